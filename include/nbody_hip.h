@@ -1,0 +1,174 @@
+/* nbody_hip.h -- C ABI of the MI355X (gfx950) N-body force-and-integrate engine.
+ *
+ * The reference (alxn3/nbody-llm) has no FFI for this path: its operator interface is the Rust
+ * trait `Simulation<F, D, P, I>` (src/shared.rs:80-97) implemented by
+ * `BruteForceSimulation` (src/manual/brute_force.rs:28-103) and `BarnesHutSimulation`
+ * (src/manual/barnes_hut.rs:205-285).  Every entry point below names the trait method (or
+ * reference function) it stands in for; INTEGRATION.md shows the Rust `extern "C"` block and the
+ * `impl Simulation` a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every call returns int: 0 = NBODY_OK, < 0 = error (nbody_last_error() has the text);
+ *     no exception or panic crosses the boundary;
+ *   - a handle is used from one thread at a time (the reference calls its simulation from one
+ *     thread: src/main.rs:119-122, src/vis.rs:537-553);
+ *   - the library owns all device memory; host buffers are caller-owned and only touched
+ *     during the call;
+ *   - bodies cross the boundary as `PointParticle<f32,3>` records (src/shared.rs:151-158,
+ *     #[repr(C)]): 10 floats {pos[3], vel[3], acc[3], mass}, stride 40 bytes;
+ *   - there is no CPU fallback: without a HIP device nbody_create fails with NBODY_ERR_NO_DEVICE.
+ */
+#ifndef NBODY_HIP_H
+#define NBODY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_ABI_VERSION 1
+
+typedef struct NbodyHandle NbodyHandle;
+
+enum {
+    NBODY_OK = 0,
+    NBODY_ERR_INVALID = -1,     /* bad argument / call not valid in this state */
+    NBODY_ERR_HIP = -2,         /* a HIP runtime call failed */
+    NBODY_ERR_CAPACITY = -3,    /* more bodies than the handle was created for */
+    NBODY_ERR_TREE_DEPTH = -4,  /* octree deeper than NBODY_MAX_TREE_DEPTH (coincident bodies): the
+                                   reference recurses without bound here (barnes_hut.rs:143-183) */
+    NBODY_ERR_COMM = -5,        /* RCCL failure */
+    NBODY_ERR_NO_DEVICE = -6    /* no usable HIP device */
+};
+
+#define NBODY_MAX_TREE_DEPTH 192
+
+/* which reference solver the handle stands in for */
+enum { NBODY_BRUTE_FORCE = 0,  /* src/manual/brute_force.rs */
+       NBODY_BARNES_HUT = 1 }; /* src/manual/barnes_hut.rs  */
+
+/* arithmetic of the force kernels */
+enum { NBODY_MATH_STRICT = 0, /* sqrt, (d*d)*d, g/r^3, no FMA contraction, partners in ascending
+                                 index order: the reference's rounding sequence */
+       NBODY_MATH_FAST = 1 }; /* v_rsq_f32, FMA, partner range split over waves: <=1e-5 relative */
+
+/* Barnes-Hut leaf semantics */
+enum { NBODY_LEAF_REFERENCE = 0 }; /* src/manual: a leaf failing the opening test contributes 0 */
+
+typedef struct NbodyConfig {
+    uint32_t struct_size;  /* = sizeof(NbodyConfig) */
+    int32_t method;        /* NBODY_BRUTE_FORCE | NBODY_BARNES_HUT */
+    int32_t math_mode;     /* NBODY_MATH_STRICT | NBODY_MATH_FAST */
+    int32_t leaf_mode;     /* NBODY_LEAF_REFERENCE */
+    int32_t device;        /* HIP device ordinal; -1 = LOCAL_RANK env or 0 */
+    int32_t rank;          /* this process's shard, 0 <= rank < world_size */
+    int32_t world_size;    /* number of shards (one process per GPU); 1 = single GPU */
+    int32_t host_threads;  /* octree-build threads (the reference's `-t`, src/main.rs:34-35); 0 = all */
+    uint64_t capacity;     /* max bodies over ALL shards (add_point may grow up to this) */
+} NbodyConfig;
+
+typedef struct NbodyStats {
+    uint64_t steps;               /* step_by calls completed */
+    uint64_t interactions;        /* bf: sum of n_own*(n_total-1) directed pairs; bh: accepted nodes */
+    uint64_t node_visits;         /* bh: opening tests evaluated (0 for bf) */
+    uint64_t tree_nodes;          /* bh: nodes in the last tree built */
+    uint64_t force_launches;      /* force-kernel launches timed since the last nbody_reset_stats */
+    double force_kernel_ms;       /* sum of their HIP-event durations (needs nbody_set_profiling(h,1)) */
+    double tree_build_ms;         /* bh: host wall time in the octree build, summed */
+    double tree_copy_ms;          /* bh: host wall time in D2H positions + H2D nodes, summed */
+    double exchange_ms;           /* multi-GPU: host wall time blocked in the exchange (0 when async) */
+} NbodyStats;
+
+/* ---- lifecycle: Simulation::new / Clone / drop ------------------------------------------- */
+/* Simulation::new(points, integrator, bounds) (shared.rs:84): bodies and bounds arrive through
+ * nbody_upload / nbody_set_bounds; the integrator is the reference's LeapFrogIntegrator
+ * (shared.rs:106-149), the only one it ships.  Settings start at SimulationSettings::default()
+ * (shared.rs:69-78): g=1, g_soft=0, dt=1e-3, theta2=0.5. */
+int nbody_create(const NbodyConfig* cfg, NbodyHandle** out);
+void nbody_destroy(NbodyHandle* h);
+/* `Clone` supertrait (shared.rs:80; BH clone drops the tree, barnes_hut.rs:113-135). */
+int nbody_clone(const NbodyHandle* h, NbodyHandle** out);
+
+/* ---- state in / out ------------------------------------------------------------------------ */
+/* Replaces the body vector (the `points: Vec<P>` argument of Simulation::new).  In a sharded run
+ * every rank passes the same full vector; the library keeps its own index block. */
+int nbody_upload(NbodyHandle* h, const void* aos, size_t n, size_t stride_bytes);
+/* Simulation::get_points (shared.rs:93).  Writes this rank's bodies (all of them when
+ * world_size == 1) in vector order; *n_out = how many. */
+int nbody_download(NbodyHandle* h, void* aos, size_t cap, size_t stride_bytes, size_t* n_out);
+/* get_points().len() of this rank's block. */
+int nbody_count(NbodyHandle* h, size_t* n_out);
+/* Sum of nbody_count over all ranks as of the last exchange (== nbody_count when world_size == 1). */
+int nbody_count_global(NbodyHandle* h, size_t* n_out);
+/* Simulation::add_point = Vec::push (brute_force.rs:92-94); single-GPU handles only. */
+int nbody_add_point(NbodyHandle* h, const void* particle);
+/* Simulation::remove_point = Vec::swap_remove (brute_force.rs:96-98); single-GPU handles only. */
+int nbody_remove_point(NbodyHandle* h, size_t index);
+
+/* ---- settings: Simulation::settings / settings_mut (shared.rs:95-96) ----------------------- */
+int nbody_set_settings(NbodyHandle* h, float g, float g_soft, float dt, float theta2);
+int nbody_get_settings(const NbodyHandle* h, float* g, float* g_soft, float* dt, float* theta2);
+/* Bounds::new(center, width) (shared.rs:236-243). */
+int nbody_set_bounds(NbodyHandle* h, const float center[3], float width);
+
+/* ---- stepping ------------------------------------------------------------------------------- */
+/* Simulation::init (brute_force.rs:47-50, barnes_hut.rs:229-236): elapsed = 0. */
+int nbody_init(NbodyHandle* h);
+/* Simulation::step_by(dt) (brute_force.rs:84-90, barnes_hut.rs:265-271): half drift, retain
+ * in-bounds bodies, forces, kick + half drift, elapsed += dt.  dt may be negative. */
+int nbody_step_by(NbodyHandle* h, float dt);
+/* k x Simulation::step() (shared.rs:86-88) with no host synchronisation in between (brute
+ * force); returns after enqueueing.  Use nbody_sync before reading a host clock. */
+int nbody_steps(NbodyHandle* h, int k);
+/* Simulation::update_forces (brute_force.rs:64-82, barnes_hut.rs:250-263). */
+int nbody_update_forces(NbodyHandle* h);
+/* Simulation::elapsed (shared.rs:94). */
+int nbody_elapsed(const NbodyHandle* h, float* out);
+/* Blocks until everything enqueued on the handle's stream has finished. */
+int nbody_sync(NbodyHandle* h);
+
+/* ---- diagnostics (no reference counterpart) -------------------------------------------------- */
+int nbody_set_profiling(NbodyHandle* h, int on); /* HIP events around every force-kernel launch */
+int nbody_stats(NbodyHandle* h, NbodyStats* out);
+int nbody_reset_stats(NbodyHandle* h);
+/* f64 kinetic and potential energy of this rank's view (world_size == 1: the whole system),
+ * evaluated on the device: KE = sum 1/2 m v^2, PE = -g sum_{i<j} m_i m_j / sqrt(r^2 + g_soft^2). */
+int nbody_energy(NbodyHandle* h, double* kinetic, double* potential);
+/* Linearised octree of the last Barnes-Hut force pass: per node {com xyz, mass}, width, skip
+ * index (first node after the subtree, depth-first pre-order).  Arrays may be NULL to count. */
+int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* skip, size_t cap, size_t* n_nodes);
+const char* nbody_last_error(const NbodyHandle* h); /* h may be NULL: last create/clone error */
+
+/* ---- multi-GPU (no reference counterpart) ------------------------ */
+#define NBODY_COMM_ID_BYTES 128
+/* rank 0 calls nbody_comm_unique_id and ships the bytes to the other ranks out of band; every
+ * rank then calls nbody_comm_init on its handle (collective). */
+int nbody_comm_unique_id(void* id_bytes);
+int nbody_comm_init(NbodyHandle* h, const void* id_bytes);
+/* first global index and length of this rank's block at upload time */
+int nbody_local_range(const NbodyHandle* h, size_t* first, size_t* count);
+
+/* ---- synthetic initial conditions (host side; what src/main.rs:52-89 does for the disc) ----- */
+/* Plummer sphere, G = M = 1, Henon units, equal masses 1/n, centre of mass at rest at the origin. */
+int nbody_ic_plummer(void* aos, size_t n, size_t stride_bytes, uint64_t seed);
+/* The reference's self-gravitating disc: 1 unit-mass star + n disc bodies (src/main.rs:52-89);
+ * writes n+1 records. */
+int nbody_ic_disc(void* aos, size_t n_disc, size_t stride_bytes, uint64_t seed);
+
+/* ---- host-only entry (no device needed): the octree build alone ------------------------------ */
+/* BarnesHutSimulation::build_tree (barnes_hut.rs:143-183) + linearisation, as the Barnes-Hut step
+ * runs it.  pos4 = n records {x,y,z,m}.  Output arrays hold `cap` nodes (com_mass: 4 floats per
+ * node) and may be NULL to count; `order` receives the n body ids in depth-first leaf order. */
+int nbody_host_build_tree(const float* pos4, size_t n, const float center[3], float width, int threads,
+                          float* com_mass, float* node_width, int32_t* skip, int32_t* leaf_body, int32_t* order,
+                          size_t cap, size_t* n_nodes);
+
+int nbody_abi_version(void);
+int nbody_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_H */

@@ -1,0 +1,345 @@
+"""nbody_llm_amd -- ctypes binding of libnbody_hip.so (include/nbody_hip.h) and a thin host-side
+mirror of the reference's `Simulation` trait (src/shared.rs:80-97) for tests and bench.py.
+
+The directory is named `nbody-llm_amd`; load it under the module name `nbody_llm_amd` with
+`__graft_entry__.load_package()` (a hyphen cannot be imported directly).
+
+There is NO fallback: if libnbody_hip.so is missing this module raises at import, and without a
+HIP device `Simulation(...)` raises NbodyError(NBODY_ERR_NO_DEVICE).  Nothing here touches
+oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbody_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C nbody-llm_amd/csrc` (or __graft_entry__.build()); "
+        "there is no Python/CPU fallback for the HIP engine"
+    )
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+# ---- constants (include/nbody_hip.h) ----------------------------------------------------------
+NBODY_OK = 0
+NBODY_ERR_INVALID = -1
+NBODY_ERR_HIP = -2
+NBODY_ERR_CAPACITY = -3
+NBODY_ERR_TREE_DEPTH = -4
+NBODY_ERR_COMM = -5
+NBODY_ERR_NO_DEVICE = -6
+BRUTE_FORCE, BARNES_HUT = 0, 1
+STRICT, FAST = 0, 1
+LEAF_REFERENCE = 0
+COMM_ID_BYTES = 128
+
+#: PointParticle<f32,3>, #[repr(C)] (src/shared.rs:151-158)
+PARTICLE_DTYPE = np.dtype(
+    [("position", "<f4", 3), ("velocity", "<f4", 3), ("acceleration", "<f4", 3), ("mass", "<f4")]
+)
+assert PARTICLE_DTYPE.itemsize == 40
+
+#: every symbol include/nbody_hip.h declares (tests check the library exports all of them)
+DECLARED_SYMBOLS = [
+    "nbody_create", "nbody_destroy", "nbody_clone", "nbody_upload", "nbody_download", "nbody_count",
+    "nbody_count_global", "nbody_add_point", "nbody_remove_point", "nbody_set_settings", "nbody_get_settings",
+    "nbody_set_bounds", "nbody_init", "nbody_step_by", "nbody_steps", "nbody_update_forces", "nbody_elapsed",
+    "nbody_sync", "nbody_set_profiling", "nbody_stats", "nbody_reset_stats", "nbody_energy", "nbody_tree_export",
+    "nbody_last_error", "nbody_comm_unique_id", "nbody_comm_init", "nbody_local_range", "nbody_ic_plummer",
+    "nbody_ic_disc", "nbody_host_build_tree", "nbody_abi_version", "nbody_device_count",
+]
+
+
+class NbodyConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("method", C.c_int32), ("math_mode", C.c_int32), ("leaf_mode", C.c_int32),
+        ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("host_threads", C.c_int32),
+        ("capacity", C.c_uint64),
+    ]
+
+
+class NbodyStats(C.Structure):
+    _fields_ = [
+        ("steps", C.c_uint64), ("interactions", C.c_uint64), ("node_visits", C.c_uint64), ("tree_nodes", C.c_uint64),
+        ("force_launches", C.c_uint64), ("force_kernel_ms", C.c_double), ("tree_build_ms", C.c_double),
+        ("tree_copy_ms", C.c_double), ("exchange_ms", C.c_double),
+    ]
+
+
+_H = C.c_void_p
+_f, _sz, _i = C.c_float, C.c_size_t, C.c_int
+_pf = C.POINTER(C.c_float)
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_sig("nbody_create", _i, C.POINTER(NbodyConfig), C.POINTER(_H))
+_sig("nbody_destroy", None, _H)
+_sig("nbody_clone", _i, _H, C.POINTER(_H))
+_sig("nbody_upload", _i, _H, C.c_void_p, _sz, _sz)
+_sig("nbody_download", _i, _H, C.c_void_p, _sz, _sz, C.POINTER(_sz))
+_sig("nbody_count", _i, _H, C.POINTER(_sz))
+_sig("nbody_count_global", _i, _H, C.POINTER(_sz))
+_sig("nbody_add_point", _i, _H, C.c_void_p)
+_sig("nbody_remove_point", _i, _H, _sz)
+_sig("nbody_set_settings", _i, _H, _f, _f, _f, _f)
+_sig("nbody_get_settings", _i, _H, _pf, _pf, _pf, _pf)
+_sig("nbody_set_bounds", _i, _H, _pf, _f)
+_sig("nbody_init", _i, _H)
+_sig("nbody_step_by", _i, _H, _f)
+_sig("nbody_steps", _i, _H, _i)
+_sig("nbody_update_forces", _i, _H)
+_sig("nbody_elapsed", _i, _H, _pf)
+_sig("nbody_sync", _i, _H)
+_sig("nbody_set_profiling", _i, _H, _i)
+_sig("nbody_stats", _i, _H, C.POINTER(NbodyStats))
+_sig("nbody_reset_stats", _i, _H)
+_sig("nbody_energy", _i, _H, C.POINTER(C.c_double), C.POINTER(C.c_double))
+_sig("nbody_tree_export", _i, _H, C.c_void_p, C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz))
+_sig("nbody_last_error", C.c_char_p, _H)
+_sig("nbody_comm_unique_id", _i, C.c_void_p)
+_sig("nbody_comm_init", _i, _H, C.c_void_p)
+_sig("nbody_local_range", _i, _H, C.POINTER(_sz), C.POINTER(_sz))
+_sig("nbody_ic_plummer", _i, C.c_void_p, _sz, _sz, C.c_uint64)
+_sig("nbody_ic_disc", _i, C.c_void_p, _sz, _sz, C.c_uint64)
+_sig("nbody_host_build_tree", _i, C.c_void_p, _sz, _pf, _f, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_void_p, _sz, C.POINTER(_sz))
+_sig("nbody_abi_version", _i)
+_sig("nbody_device_count", _i)
+
+
+class NbodyError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"nbody error {code}: {msg}")
+        self.code = code
+
+
+def device_count() -> int:
+    return int(lib.nbody_device_count())
+
+
+def plummer(n: int, seed: int = 20250523) -> np.ndarray:
+    """Plummer sphere in Henon units as PointParticle records (host side, f64 -> f32)."""
+    out = np.zeros(n, dtype=PARTICLE_DTYPE)
+    rc = lib.nbody_ic_plummer(out.ctypes.data, n, 40, seed)
+    if rc:
+        raise NbodyError(rc, "nbody_ic_plummer")
+    return out
+
+
+def disc(n_disc: int, seed: int = 20250523) -> np.ndarray:
+    """The reference's self-gravitating disc (src/main.rs:52-89): 1 star + n_disc bodies."""
+    out = np.zeros(n_disc + 1, dtype=PARTICLE_DTYPE)
+    rc = lib.nbody_ic_disc(out.ctypes.data, n_disc, 40, seed)
+    if rc:
+        raise NbodyError(rc, "nbody_ic_disc")
+    return out
+
+
+def host_build_tree(pos4: np.ndarray, center, width: float, threads: int = 1):
+    """Host-only octree build (no device).  Returns dict(com_mass, width, skip, leaf_body, order)."""
+    pos4 = np.ascontiguousarray(pos4, dtype=np.float32).reshape(-1, 4)
+    n = pos4.shape[0]
+    c = (C.c_float * 3)(*[float(x) for x in center])
+    nn = C.c_size_t(0)
+    rc = lib.nbody_host_build_tree(pos4.ctypes.data, n, c, width, threads, None, None, None, None, None, 0, C.byref(nn))
+    if rc:
+        raise NbodyError(rc, "nbody_host_build_tree")
+    m = nn.value
+    com = np.zeros((m, 4), np.float32)
+    w = np.zeros(m, np.float32)
+    skip = np.zeros(m, np.int32)
+    body = np.zeros(m, np.int32)
+    order = np.zeros(n, np.int32)
+    rc = lib.nbody_host_build_tree(pos4.ctypes.data, n, c, width, threads, com.ctypes.data, w.ctypes.data,
+                                   skip.ctypes.data, body.ctypes.data, order.ctypes.data, m, C.byref(nn))
+    if rc:
+        raise NbodyError(rc, "nbody_host_build_tree")
+    return dict(com_mass=com, width=w, skip=skip, leaf_body=body, order=order)
+
+
+@dataclass
+class Settings:
+    """SimulationSettings (src/shared.rs:61-78)."""
+    g: float = 1.0
+    g_soft: float = 0.0
+    dt: float = 1e-3
+    theta2: float = 0.5
+
+
+class Simulation:
+    """Host-side mirror of the reference's `Simulation` trait over the C ABI.
+
+    `Simulation(points, center, width, method=...)` is `Simulation::new(points, LeapFrogIntegrator,
+    Bounds::new(center, width))`; methods keep the trait's names and meaning.
+    """
+
+    def __init__(self, points: np.ndarray, center=(0.0, 0.0, 0.0), width: float = 1.0, *, method: int = BRUTE_FORCE,
+                 math_mode: int = STRICT, capacity: int | None = None, device: int = -1, rank: int = 0,
+                 world_size: int = 1, host_threads: int = 0, _handle=None):
+        self._h = _H()
+        if _handle is not None:
+            self._h = _handle
+            return
+        points = np.ascontiguousarray(points, dtype=PARTICLE_DTYPE)
+        cfg = NbodyConfig(C.sizeof(NbodyConfig), method, math_mode, LEAF_REFERENCE, device, rank, world_size,
+                          host_threads, int(capacity if capacity is not None else max(1, points.shape[0])))
+        rc = lib.nbody_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            self._h = _H()
+            raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
+        self._check(lib.nbody_set_bounds(self._h, (C.c_float * 3)(*[float(x) for x in center]), float(width)))
+        self._check(lib.nbody_upload(self._h, points.ctypes.data, points.shape[0], 40))
+
+    # -- plumbing
+    def _check(self, rc: int):
+        if rc:
+            raise NbodyError(rc, (lib.nbody_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            lib.nbody_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- the trait surface (shared.rs:80-97)
+    def init(self):
+        self._check(lib.nbody_init(self._h))
+
+    def step(self):
+        self._check(lib.nbody_steps(self._h, 1))
+
+    def steps(self, k: int):
+        self._check(lib.nbody_steps(self._h, int(k)))
+
+    def step_by(self, dt: float):
+        self._check(lib.nbody_step_by(self._h, float(dt)))
+
+    def update_forces(self):
+        self._check(lib.nbody_update_forces(self._h))
+
+    def add_point(self, particle: np.ndarray):
+        p = np.ascontiguousarray(particle, dtype=PARTICLE_DTYPE).reshape(1)
+        self._check(lib.nbody_add_point(self._h, p.ctypes.data))
+
+    def remove_point(self, index: int):
+        self._check(lib.nbody_remove_point(self._h, int(index)))
+
+    def get_points(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._check(lib.nbody_count(self._h, C.byref(n)))
+        out = np.zeros(n.value, dtype=PARTICLE_DTYPE)
+        self._check(lib.nbody_download(self._h, out.ctypes.data, n.value, 40, C.byref(n)))
+        return out[: n.value]
+
+    def __len__(self) -> int:
+        n = C.c_size_t(0)
+        self._check(lib.nbody_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def count_global(self) -> int:
+        n = C.c_size_t(0)
+        self._check(lib.nbody_count_global(self._h, C.byref(n)))
+        return int(n.value)
+
+    def elapsed(self) -> float:
+        v = C.c_float(0)
+        self._check(lib.nbody_elapsed(self._h, C.byref(v)))
+        return float(v.value)
+
+    @property
+    def settings(self) -> Settings:
+        g, e, dt, t2 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        self._check(lib.nbody_get_settings(self._h, C.byref(g), C.byref(e), C.byref(dt), C.byref(t2)))
+        return Settings(g.value, e.value, dt.value, t2.value)
+
+    @settings.setter
+    def settings(self, s: Settings):
+        self._check(lib.nbody_set_settings(self._h, float(s.g), float(s.g_soft), float(s.dt), float(s.theta2)))
+
+    def set_bounds(self, center, width: float):
+        self._check(lib.nbody_set_bounds(self._h, (C.c_float * 3)(*[float(x) for x in center]), float(width)))
+
+    def clone(self) -> "Simulation":
+        h = _H()
+        rc = lib.nbody_clone(self._h, C.byref(h))
+        if rc:
+            raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
+        return Simulation(None, _handle=h)
+
+    # -- diagnostics / multi-GPU
+    def sync(self):
+        self._check(lib.nbody_sync(self._h))
+
+    def set_profiling(self, on: bool):
+        self._check(lib.nbody_set_profiling(self._h, int(bool(on))))
+
+    def stats(self) -> NbodyStats:
+        s = NbodyStats()
+        self._check(lib.nbody_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(lib.nbody_reset_stats(self._h))
+
+    def energy(self) -> tuple[float, float]:
+        ke, pe = C.c_double(), C.c_double()
+        self._check(lib.nbody_energy(self._h, C.byref(ke), C.byref(pe)))
+        return float(ke.value), float(pe.value)
+
+    def tree(self):
+        n = C.c_size_t(0)
+        self._check(lib.nbody_tree_export(self._h, None, None, None, 0, C.byref(n)))
+        m = n.value
+        com = np.zeros((m, 4), np.float32)
+        w = np.zeros(m, np.float32)
+        skip = np.zeros(m, np.int32)
+        self._check(lib.nbody_tree_export(self._h, com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, C.byref(n)))
+        return dict(com_mass=com, width=w, skip=skip)
+
+    def local_range(self) -> tuple[int, int]:
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self._check(lib.nbody_local_range(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def comm_init(self, id_bytes: bytes):
+        buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
+        self._check(lib.nbody_comm_init(self._h, buf))
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.nbody_comm_unique_id(buf)
+    if rc:
+        raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
+    return buf.raw
+
+
+def shard_range(n: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Index block [lo, hi) that nbody_upload gives `rank` (contiguous blocks of ceil(n/G))."""
+    blk = (n + world_size - 1) // world_size
+    lo = min(n, rank * blk)
+    return lo, min(n, lo + blk)

@@ -1,0 +1,60 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (internal to libnbody_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace nbody {
+
+// Device-resident body state of one shard.  Positions of ALL shards live in `pos_all`
+// (world_size segments of `seg_cap` float4 {x,y,z,m}); velocities and accelerations only for
+// the shard's own segment.  Body counts are device-resident so that bodies can leave the box
+// (Vec::retain, brute_force.rs:86) without a host round trip.
+struct Shard {
+    float4* pos_all = nullptr;   // [n_seg * seg_cap]  {x, y, z, mass}
+    float4* vel = nullptr;       // [seg_cap]          {vx, vy, vz, 0}
+    float4* acc = nullptr;       // [seg_cap]          {ax, ay, az, 0}
+    int* seg_count = nullptr;    // [n_seg] bodies alive per segment
+    int* escaped = nullptr;      // [1] bodies of the own segment flagged out of bounds by drift
+    unsigned char* keep = nullptr;  // [seg_cap] 1 = in bounds
+    int n_seg = 1;
+    int seg_cap = 0;
+    int my_seg = 0;
+    float4* own_pos() const { return pos_all + size_t(my_seg) * seg_cap; }
+    int* own_count() const { return seg_count + my_seg; }
+};
+
+struct BoundsF {  // Bounds::min()/max() (shared.rs:223-229) evaluated once on the host in f32
+    float lo[3];
+    float hi[3];
+};
+
+// K0: PointParticle<f32,3> AoS (stride in floats) <-> SoA
+void launch_aos_to_soa(hipStream_t s, const float* aos, int stride_f, int n, float4* pos, float4* vel, float4* acc);
+void launch_soa_to_aos(hipStream_t s, float* aos, int stride_f, int n, const float4* pos, const float4* vel, const float4* acc);
+
+// K1: integrate_pre_force (shared.rs:135-140) + Bounds::contains flags (shared.rs:210-212)
+void launch_drift_half(hipStream_t s, const Shard& sh, int n_upper, float dt, BoundsF b);
+// K4: Vec::retain (brute_force.rs:86): in-place order-preserving compaction, no-op unless *escaped
+void launch_compact(hipStream_t s, const Shard& sh);
+// K3: integrate_after_force (shared.rs:141-148)
+void launch_kick_drift(hipStream_t s, const Shard& sh, int n_upper, float dt);
+
+// K2: BruteForceSimulation::update_forces (brute_force.rs:64-82)
+void launch_bf_forces_strict(hipStream_t s, const Shard& sh, int n_upper, float g, float g_soft2);
+void launch_bf_forces_fast(hipStream_t s, const Shard& sh, int n_upper, float g, float g_soft2);
+
+// K5: BarnesHutSimulation::calc_force (barnes_hut.rs:185-203) over a linearised octree
+struct TreeDev {
+    const float4* node_a = nullptr;  // {com.x, com.y, com.z, mass}
+    const float4* node_b = nullptr;  // {width^2, skip (int bits), unused, unused}
+    int n_nodes = 0;
+    const int* order = nullptr;      // own bodies (index into the own segment) in tree order
+    int n_order = 0;
+};
+void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
+                    int fast_math, unsigned long long* counters /* [2]: accepted, visited */);
+
+// diagnostics: f64 energies of the own segment against all segments; out = {KE, PE_pairs_sum}
+void launch_energy(hipStream_t s, const Shard& sh, int n_upper, double g_soft2, double* out2);
+
+}  // namespace nbody

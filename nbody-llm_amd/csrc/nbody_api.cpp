@@ -1,0 +1,775 @@
+// nbody_api.cpp -- the C ABI of include/nbody_hip.h: host orchestration of one shard.
+//
+// One handle = one reference `Simulation` object (src/shared.rs:80-97) living on one GPU.
+// step_by follows brute_force.rs:84-90 / barnes_hut.rs:265-271 kernel by kernel:
+//   K1 drift_half -> K4 compact (retain) -> [exchange] -> K2 | (host octree + K5) -> K3 kick_drift
+// Everything is enqueued on the handle's own stream; the brute-force path never synchronises
+// with the host inside nbody_steps, the Barnes-Hut path must (the octree is built on the host).
+#include "../../include/nbody_hip.h"
+#include "kernels.h"
+#include "octree_host.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace nbody { extern int g_bf_fast_variant; }
+
+using nbody::BoundsF;
+using nbody::Shard;
+
+struct NbodyHandle {
+    NbodyConfig cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Shard sh;
+    float g = 1.0f, g_soft = 0.0f, dt = 1e-3f, theta2 = 0.5f;  // shared.rs:69-78
+    float center[3] = {0.f, 0.f, 0.f};
+    float width = 0.f;
+    BoundsF bnd{};
+    bool bounds_set = false;
+    float elapsed = 0.f;
+
+    size_t n_local = 0;        // host view of the own body count (an upper bound while count_dirty)
+    bool count_dirty = false;  // drift may have dropped bodies since n_local was read
+    std::vector<int> seg_count_host;  // host view of every segment's count (upper bounds likewise)
+    size_t first_global = 0, n_at_upload = 0;
+
+    float* d_aos = nullptr;    // device staging for PointParticle records
+    float* h_aos = nullptr;    // pinned host staging
+    size_t aos_cap = 0;        // records
+
+    // Barnes-Hut
+    std::unique_ptr<nbody::WorkerPool> pool;
+    nbody::HostTree tree;
+    float4* d_node_a = nullptr;
+    float4* d_node_b = nullptr;
+    int* d_order = nullptr;
+    size_t d_node_cap = 0, d_order_cap = 0;
+    float* h_pos = nullptr;    // pinned: all segments' positions
+    int* h_counts = nullptr;   // pinned: all segments' counts
+    std::vector<int32_t> own_order;
+    unsigned long long* d_counters = nullptr;  // [2] accepted, visited
+    unsigned long long* h_counters = nullptr;  // pinned
+
+    // diagnostics
+    NbodyStats stats{};
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
+    double* d_energy = nullptr;
+    size_t energy_blocks = 0;
+
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    bool comm_ready = false;
+
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+int fail(NbodyHandle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, NBODY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+#define NCCL_TRY(h, expr)                                                                             \
+    do {                                                                                              \
+        ncclResult_t r_ = (expr);                                                                     \
+        if (r_ != ncclSuccess)                                                                        \
+            return fail(h, NBODY_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));       \
+    } while (0)
+
+void* pinned_alloc(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void pinned_free(void* p) { (void)hipHostFree(p); }
+
+int use_device(NbodyHandle* h) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    return NBODY_OK;
+}
+
+void compute_bounds(NbodyHandle* h) {
+    float hw = h->width * 0.5f;  // Bounds::new
+    for (int i = 0; i < 3; ++i) {
+        h->bnd.lo[i] = h->center[i] + (-hw);  // add_scalar(-half_width), shared.rs:224
+        h->bnd.hi[i] = h->center[i] + hw;     // shared.rs:228
+    }
+}
+
+int ensure_aos(NbodyHandle* h, size_t records) {
+    if (records <= h->aos_cap) return NBODY_OK;
+    if (h->d_aos) (void)hipFree(h->d_aos);
+    if (h->h_aos) (void)hipHostFree(h->h_aos);
+    h->d_aos = nullptr; h->h_aos = nullptr; h->aos_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_aos, records * 10 * sizeof(float)));
+    HIP_TRY(h, hipHostMalloc(&h->h_aos, records * 10 * sizeof(float), hipHostMallocDefault));
+    h->aos_cap = records;
+    return NBODY_OK;
+}
+
+// refresh the host view of the own count (one 4-byte D2H + sync), only when it may be stale
+int sync_count(NbodyHandle* h) {
+    if (!h->count_dirty) return NBODY_OK;
+    HIP_TRY(h, hipMemcpyAsync(h->h_counts, h->sh.seg_count, sizeof(int) * h->sh.n_seg, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int s = 0; s < h->sh.n_seg; ++s) h->seg_count_host[s] = h->h_counts[s];
+    h->n_local = size_t(h->h_counts[h->sh.my_seg]);
+    h->count_dirty = false;
+    return NBODY_OK;
+}
+
+int push_counts(NbodyHandle* h) {
+    for (int s = 0; s < h->sh.n_seg; ++s) h->h_counts[s] = h->seg_count_host[s];
+    HIP_TRY(h, hipMemcpyAsync(h->sh.seg_count, h->h_counts, sizeof(int) * h->sh.n_seg, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // h_counts is reused
+    return NBODY_OK;
+}
+
+size_t total_upper(const NbodyHandle* h) {
+    size_t t = 0;
+    for (int c : h->seg_count_host) t += size_t(c);
+    return t;
+}
+
+// the once-per-step exchange of half-drifted positions: an in-place
+// all-gather of the own segment into every rank's pos_all, plus the live counts
+int exchange(NbodyHandle* h) {
+    if (h->sh.n_seg == 1) return NBODY_OK;
+    if (!h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    NCCL_TRY(h, ncclGroupStart());
+    NCCL_TRY(h, ncclAllGather(h->sh.own_pos(), h->sh.pos_all, size_t(h->sh.seg_cap) * 4, ncclFloat, h->comm, h->stream));
+    NCCL_TRY(h, ncclAllGather(h->sh.own_count(), h->sh.seg_count, 1, ncclInt32, h->comm, h->stream));
+    NCCL_TRY(h, ncclGroupEnd());
+    return NBODY_OK;
+}
+
+struct ForceTimer {  // HIP events around a force-kernel launch, on the launch stream
+    NbodyHandle* h;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    explicit ForceTimer(NbodyHandle* hh) : h(hh) {
+        if (!h->profiling) return;
+        if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
+        else {
+            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) { ev = {nullptr, nullptr}; return; }
+        }
+        (void)hipEventRecord(ev.first, h->stream);
+    }
+    ~ForceTimer() {
+        if (!ev.first) return;
+        (void)hipEventRecord(ev.second, h->stream);
+        h->ev_pending.push_back(ev);
+    }
+};
+
+int drain_events(NbodyHandle* h) {
+    if (h->ev_pending.empty()) return NBODY_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (auto& ev : h->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+            h->stats.force_kernel_ms += ms;
+            h->stats.force_launches += 1;
+        }
+        h->ev_free.push_back(ev);
+    }
+    h->ev_pending.clear();
+    return NBODY_OK;
+}
+
+int bf_forces(NbodyHandle* h) {
+    const float eps2 = h->g_soft * h->g_soft;  // brute_force.rs:69
+    {
+        ForceTimer t(h);
+        if (h->cfg.math_mode == NBODY_MATH_STRICT) nbody::launch_bf_forces_strict(h->stream, h->sh, int(h->n_local), h->g, eps2);
+        else nbody::launch_bf_forces_fast(h->stream, h->sh, int(h->n_local), h->g, eps2);
+    }
+    HIP_TRY(h, hipGetLastError());
+    size_t tot = total_upper(h);
+    if (tot > 0) h->stats.interactions += uint64_t(h->n_local) * uint64_t(tot - 1);
+    return NBODY_OK;
+}
+
+int ensure_tree_dev(NbodyHandle* h, size_t nodes, size_t order) {
+    if (nodes > h->d_node_cap) {
+        if (h->d_node_a) (void)hipFree(h->d_node_a);
+        if (h->d_node_b) (void)hipFree(h->d_node_b);
+        h->d_node_a = h->d_node_b = nullptr; h->d_node_cap = 0;
+        size_t cap = nodes + nodes / 4 + 1024;
+        HIP_TRY(h, hipMalloc(&h->d_node_a, cap * sizeof(float4)));
+        HIP_TRY(h, hipMalloc(&h->d_node_b, cap * sizeof(float4)));
+        h->d_node_cap = cap;
+    }
+    if (order > h->d_order_cap) {
+        if (h->d_order) (void)hipFree(h->d_order);
+        h->d_order = nullptr; h->d_order_cap = 0;
+        size_t cap = order + order / 4 + 1024;
+        HIP_TRY(h, hipMalloc(&h->d_order, cap * sizeof(int)));
+        h->d_order_cap = cap;
+    }
+    return NBODY_OK;
+}
+
+// BarnesHutSimulation::update_forces (barnes_hut.rs:250-263): rebuild the tree from the current
+// positions, then one walk per body.
+int bh_forces(NbodyHandle* h) {
+    Shard& sh = h->sh;
+    auto t0 = clk::now();
+    // positions of every segment (upper-bound counts) + the live counts, one sync
+    for (int s = 0; s < sh.n_seg; ++s) {
+        size_t cnt = size_t(h->seg_count_host[s]);
+        if (cnt)
+            HIP_TRY(h, hipMemcpyAsync(h->h_pos + 4 * size_t(s) * sh.seg_cap, sh.pos_all + size_t(s) * sh.seg_cap,
+                                      cnt * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int) * sh.n_seg, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int s = 0; s < sh.n_seg; ++s) h->seg_count_host[s] = h->h_counts[s];
+    h->n_local = size_t(h->h_counts[sh.my_seg]);
+    h->count_dirty = false;
+    double copy_ms = ms_since(t0);
+
+    auto t1 = clk::now();
+    nbody::build_octree(h->h_pos, sh.n_seg, sh.seg_cap, h->h_counts, h->center, h->width, *h->pool, h->tree);
+    if (h->tree.too_deep) return fail(h, NBODY_ERR_TREE_DEPTH, "octree deeper than NBODY_MAX_TREE_DEPTH (coincident bodies?)");
+    // bodies of the own segment in tree order (ids are s*seg_cap + j)
+    const int32_t* order = h->tree.order;
+    size_t n_order = h->tree.n_order;
+    if (sh.n_seg > 1) {
+        h->own_order.clear();
+        const int lo = sh.my_seg * sh.seg_cap, hi = lo + sh.seg_cap;
+        for (size_t k = 0; k < h->tree.n_order; ++k) {
+            int id = h->tree.order[k];
+            if (id >= lo && id < hi) h->own_order.push_back(id - lo);
+        }
+        order = h->own_order.data();
+        n_order = h->own_order.size();
+    }
+    h->stats.tree_build_ms += ms_since(t1);
+    h->stats.tree_nodes = h->tree.n_nodes;
+
+    auto t2 = clk::now();
+    int rc = ensure_tree_dev(h, h->tree.n_nodes, n_order);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_node_a, h->tree.a, h->tree.n_nodes * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_node_b, h->tree.b, h->tree.n_nodes * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    if (n_order) HIP_TRY(h, hipMemcpyAsync(h->d_order, order, n_order * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (sh.n_seg > 1) HIP_TRY(h, hipStreamSynchronize(h->stream));  // own_order is pageable and reused
+    h->stats.tree_copy_ms += copy_ms + ms_since(t2);
+
+    nbody::TreeDev td;
+    td.node_a = h->d_node_a; td.node_b = h->d_node_b; td.n_nodes = int(h->tree.n_nodes);
+    td.order = h->d_order; td.n_order = int(n_order);
+    {
+        ForceTimer t(h);
+        nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
+                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+int forces(NbodyHandle* h) {
+    return h->cfg.method == NBODY_BARNES_HUT ? bh_forces(h) : bf_forces(h);
+}
+
+int step_impl(NbodyHandle* h, float dt) {
+    if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+    Shard& sh = h->sh;
+    nbody::launch_drift_half(h->stream, sh, int(h->n_local), dt, h->bnd);  // integrate_pre_force
+    nbody::launch_compact(h->stream, sh);                                   // retain
+    h->count_dirty = true;
+    int rc = exchange(h);
+    if (rc) return rc;
+    rc = forces(h);                                                         // update_forces
+    if (rc) return rc;
+    nbody::launch_kick_drift(h->stream, sh, int(h->n_local), dt);           // integrate_after_force
+    HIP_TRY(h, hipGetLastError());
+    h->elapsed += dt;                                                       // elapsed += dt
+    h->stats.steps += 1;
+    return NBODY_OK;
+}
+
+void free_all(NbodyHandle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
+    for (auto& ev : h->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    h->tree.clear();
+    void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
+                   h->d_node_a, h->d_node_b, h->d_order, h->d_counters, h->d_energy};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters};
+    for (void* p : host) if (p) (void)hipHostFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
+    if (!cfg || !out) return fail(nullptr, NBODY_ERR_INVALID, "null argument");
+    if (cfg->struct_size != sizeof(NbodyConfig)) return fail(nullptr, NBODY_ERR_INVALID, "NbodyConfig.struct_size mismatch");
+    if (cfg->method != NBODY_BRUTE_FORCE && cfg->method != NBODY_BARNES_HUT) return fail(nullptr, NBODY_ERR_INVALID, "unknown method");
+    if (cfg->math_mode != NBODY_MATH_STRICT && cfg->math_mode != NBODY_MATH_FAST) return fail(nullptr, NBODY_ERR_INVALID, "unknown math_mode");
+    if (cfg->leaf_mode != NBODY_LEAF_REFERENCE) return fail(nullptr, NBODY_ERR_INVALID, "unknown leaf_mode");
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, NBODY_ERR_INVALID, "bad rank/world_size");
+    if (cfg->capacity == 0 || cfg->capacity > (1ull << 30)) return fail(nullptr, NBODY_ERR_INVALID, "capacity must be in [1, 2^30]");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, NBODY_ERR_NO_DEVICE, "no HIP device (this library has no CPU fallback)");
+    int dev = cfg->device;
+    if (dev < 0) {
+        const char* lr = std::getenv("LOCAL_RANK");
+        dev = lr ? std::atoi(lr) % ndev : 0;
+    }
+    if (dev >= ndev) return fail(nullptr, NBODY_ERR_INVALID, "device ordinal out of range");
+
+    NbodyHandle* h = new NbodyHandle();
+    h->cfg = *cfg;
+    h->device = dev;
+    *out = nullptr;
+    auto bail = [&](int rc) { g_create_err = h->err; free_all(h); return rc; };
+#define CREATE_TRY(expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(NBODY_ERR_HIP); } \
+    } while (0)
+    CREATE_TRY(hipSetDevice(dev));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    Shard& sh = h->sh;
+    sh.n_seg = cfg->world_size;
+    sh.my_seg = cfg->rank;
+    sh.seg_cap = int((cfg->capacity + cfg->world_size - 1) / cfg->world_size);
+    const size_t cap = size_t(sh.seg_cap);
+    CREATE_TRY(hipMalloc(&sh.pos_all, size_t(sh.n_seg) * cap * sizeof(float4)));
+    CREATE_TRY(hipMalloc(&sh.vel, cap * sizeof(float4)));
+    CREATE_TRY(hipMalloc(&sh.acc, cap * sizeof(float4)));
+    CREATE_TRY(hipMalloc(&sh.seg_count, sizeof(int) * sh.n_seg));
+    CREATE_TRY(hipMalloc(&sh.escaped, sizeof(int)));
+    CREATE_TRY(hipMalloc(&sh.keep, cap));
+    CREATE_TRY(hipMemsetAsync(sh.pos_all, 0, size_t(sh.n_seg) * cap * sizeof(float4), h->stream));
+    CREATE_TRY(hipMemsetAsync(sh.vel, 0, cap * sizeof(float4), h->stream));
+    CREATE_TRY(hipMemsetAsync(sh.acc, 0, cap * sizeof(float4), h->stream));
+    CREATE_TRY(hipMemsetAsync(sh.seg_count, 0, sizeof(int) * sh.n_seg, h->stream));
+    CREATE_TRY(hipMemsetAsync(sh.escaped, 0, sizeof(int), h->stream));
+    CREATE_TRY(hipMemsetAsync(sh.keep, 1, cap, h->stream));
+    CREATE_TRY(hipHostMalloc(&h->h_counts, sizeof(int) * sh.n_seg, hipHostMallocDefault));
+    h->seg_count_host.assign(sh.n_seg, 0);
+    if (cfg->method == NBODY_BARNES_HUT) {
+        int threads = cfg->host_threads > 0 ? cfg->host_threads : int(std::thread::hardware_concurrency());
+        if (threads < 1) threads = 1;
+        h->pool.reset(new nbody::WorkerPool(threads));
+        h->tree.alloc = pinned_alloc;
+        h->tree.release = pinned_free;
+        CREATE_TRY(hipHostMalloc(&h->h_pos, size_t(sh.n_seg) * cap * sizeof(float4), hipHostMallocDefault));
+        CREATE_TRY(hipMalloc(&h->d_counters, 2 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+        CREATE_TRY(hipHostMalloc(&h->h_counters, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody::g_bf_fast_variant = std::atoi(v);
+    *out = h;
+    return NBODY_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C entry points
+extern "C" {
+
+int nbody_abi_version(void) { return NBODY_ABI_VERSION; }
+
+int nbody_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* nbody_last_error(const NbodyHandle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int nbody_create(const NbodyConfig* cfg, NbodyHandle** out) { return create_impl(cfg, out); }
+
+void nbody_destroy(NbodyHandle* h) { free_all(h); }
+
+int nbody_clone(const NbodyHandle* src, NbodyHandle** out) {
+    if (!src || !out) return fail(nullptr, NBODY_ERR_INVALID, "null argument");
+    NbodyHandle* s = const_cast<NbodyHandle*>(src);
+    int rc = use_device(s);
+    if (rc) return rc;
+    rc = sync_count(s);
+    if (rc) return rc;
+    NbodyHandle* h = nullptr;
+    rc = create_impl(&src->cfg, &h);
+    if (rc) return rc;
+    const Shard& a = src->sh;
+    const size_t cap = size_t(a.seg_cap);
+    hipError_t e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->sh.pos_all, a.pos_all, size_t(a.n_seg) * cap * sizeof(float4), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->sh.vel, a.vel, cap * sizeof(float4), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->sh.acc, a.acc, cap * sizeof(float4), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->sh.seg_count, a.seg_count, sizeof(int) * a.n_seg, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        g_create_err = std::string("clone copy: ") + hipGetErrorString(e);
+        free_all(h);
+        return NBODY_ERR_HIP;
+    }
+    h->g = src->g; h->g_soft = src->g_soft; h->dt = src->dt; h->theta2 = src->theta2;
+    std::memcpy(h->center, src->center, sizeof(h->center));
+    h->width = src->width; h->bnd = src->bnd; h->bounds_set = src->bounds_set;
+    h->elapsed = src->elapsed;
+    h->n_local = src->n_local;
+    h->seg_count_host = src->seg_count_host;
+    h->first_global = src->first_global; h->n_at_upload = src->n_at_upload;
+    // like the reference's BH clone (barnes_hut.rs:113-135) the tree is not carried over; neither
+    // are the communicator (call nbody_comm_init on the clone) and the statistics
+    *out = h;
+    return NBODY_OK;
+}
+
+int nbody_upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
+    if (!h || (!aos && n)) return fail(h, NBODY_ERR_INVALID, "null argument");
+    if (stride < 40 || stride % 4) return fail(h, NBODY_ERR_INVALID, "stride must be a multiple of 4 and >= 40 bytes");
+    if (n > h->cfg.capacity) return fail(h, NBODY_ERR_CAPACITY, "more bodies than NbodyConfig.capacity");
+    int rc = use_device(h);
+    if (rc) return rc;
+    Shard& sh = h->sh;
+    const size_t G = size_t(sh.n_seg);
+    const size_t blk = (n + G - 1) / G;  // contiguous index blocks keep the ascending-partner order
+    rc = ensure_aos(h, n);
+    if (rc) return rc;
+    const char* src = static_cast<const char*>(aos);
+    for (size_t k = 0; k < n; ++k) std::memcpy(h->h_aos + 10 * k, src + k * stride, 40);
+    if (n) HIP_TRY(h, hipMemcpyAsync(h->d_aos, h->h_aos, n * 40, hipMemcpyHostToDevice, h->stream));
+    for (size_t s = 0; s < G; ++s) {
+        size_t lo = std::min(n, s * blk), hi = std::min(n, lo + blk);
+        h->seg_count_host[s] = int(hi - lo);
+        bool own = int(s) == sh.my_seg;
+        nbody::launch_aos_to_soa(h->stream, h->d_aos + 10 * lo, 10, int(hi - lo), sh.pos_all + s * size_t(sh.seg_cap),
+                                 own ? sh.vel : nullptr, own ? sh.acc : nullptr);
+        if (own) { h->first_global = lo; h->n_at_upload = hi - lo; h->n_local = hi - lo; }
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemsetAsync(sh.escaped, 0, sizeof(int), h->stream));
+    h->count_dirty = false;
+    return push_counts(h);
+}
+
+int nbody_download(NbodyHandle* h, void* aos, size_t cap, size_t stride, size_t* n_out) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (stride < 40 || stride % 4) return fail(h, NBODY_ERR_INVALID, "stride must be a multiple of 4 and >= 40 bytes");
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = sync_count(h);
+    if (rc) return rc;
+    const size_t n = h->n_local;
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "download buffer too small");
+    if (n == 0) return NBODY_OK;
+    if (!aos) return fail(h, NBODY_ERR_INVALID, "null buffer");
+    rc = ensure_aos(h, n);
+    if (rc) return rc;
+    nbody::launch_soa_to_aos(h->stream, h->d_aos, 10, int(n), h->sh.own_pos(), h->sh.vel, h->sh.acc);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->h_aos, h->d_aos, n * 40, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    char* dst = static_cast<char*>(aos);
+    for (size_t k = 0; k < n; ++k) std::memcpy(dst + k * stride, h->h_aos + 10 * k, 40);
+    return NBODY_OK;
+}
+
+int nbody_count(NbodyHandle* h, size_t* n_out) {
+    if (!h || !n_out) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = sync_count(h);
+    if (rc) return rc;
+    *n_out = h->n_local;
+    return NBODY_OK;
+}
+
+int nbody_count_global(NbodyHandle* h, size_t* n_out) {
+    if (!h || !n_out) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = sync_count(h);
+    if (rc) return rc;
+    *n_out = total_upper(h);
+    return NBODY_OK;
+}
+
+int nbody_add_point(NbodyHandle* h, const void* particle) {
+    if (!h || !particle) return NBODY_ERR_INVALID;
+    if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "add_point is only supported on single-GPU handles");
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = sync_count(h);
+    if (rc) return rc;
+    if (h->n_local >= size_t(h->sh.seg_cap)) return fail(h, NBODY_ERR_CAPACITY, "capacity exhausted");
+    const float* p = static_cast<const float*>(particle);
+    float4 rec[3] = {make_float4(p[0], p[1], p[2], p[9]), make_float4(p[3], p[4], p[5], 0.f), make_float4(p[6], p[7], p[8], 0.f)};
+    const size_t k = h->n_local;
+    HIP_TRY(h, hipMemcpyAsync(h->sh.pos_all + k, &rec[0], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sh.vel + k, &rec[1], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sh.acc + k, &rec[2], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_local = k + 1;
+    h->seg_count_host[0] = int(h->n_local);
+    return push_counts(h);
+}
+
+int nbody_remove_point(NbodyHandle* h, size_t index) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "remove_point is only supported on single-GPU handles");
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = sync_count(h);
+    if (rc) return rc;
+    if (index >= h->n_local) return fail(h, NBODY_ERR_INVALID, "swap_remove index out of range");  // Vec::swap_remove panics
+    const size_t last = h->n_local - 1;
+    if (index != last) {
+        HIP_TRY(h, hipMemcpyAsync(h->sh.pos_all + index, h->sh.pos_all + last, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->sh.vel + index, h->sh.vel + last, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->sh.acc + index, h->sh.acc + last, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->n_local = last;
+    h->seg_count_host[0] = int(last);
+    return push_counts(h);
+}
+
+int nbody_set_settings(NbodyHandle* h, float g, float g_soft, float dt, float theta2) {
+    if (!h) return NBODY_ERR_INVALID;
+    h->g = g; h->g_soft = g_soft; h->dt = dt; h->theta2 = theta2;
+    return NBODY_OK;
+}
+
+int nbody_get_settings(const NbodyHandle* h, float* g, float* g_soft, float* dt, float* theta2) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (g) *g = h->g;
+    if (g_soft) *g_soft = h->g_soft;
+    if (dt) *dt = h->dt;
+    if (theta2) *theta2 = h->theta2;
+    return NBODY_OK;
+}
+
+int nbody_set_bounds(NbodyHandle* h, const float center[3], float width) {
+    if (!h || !center) return NBODY_ERR_INVALID;
+    std::memcpy(h->center, center, sizeof(h->center));
+    h->width = width;
+    compute_bounds(h);
+    h->bounds_set = true;
+    return NBODY_OK;
+}
+
+int nbody_init(NbodyHandle* h) {
+    if (!h) return NBODY_ERR_INVALID;
+    h->elapsed = 0.f;  // brute_force.rs:49; the reference's BH init also builds a tree that the
+                       // first update_forces rebuilds before any use (barnes_hut.rs:232-235, 251-254)
+    return NBODY_OK;
+}
+
+int nbody_step_by(NbodyHandle* h, float dt) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    return step_impl(h, dt);
+}
+
+int nbody_steps(NbodyHandle* h, int k) {
+    if (!h || k < 0) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    for (int i = 0; i < k; ++i) {
+        rc = step_impl(h, h->dt);  // Simulation::step, shared.rs:86-88
+        if (rc) return rc;
+    }
+    return NBODY_OK;
+}
+
+int nbody_update_forces(NbodyHandle* h) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->cfg.method == NBODY_BARNES_HUT && !h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+    rc = exchange(h);
+    if (rc) return rc;
+    return forces(h);
+}
+
+int nbody_elapsed(const NbodyHandle* h, float* out) {
+    if (!h || !out) return NBODY_ERR_INVALID;
+    *out = h->elapsed;
+    return NBODY_OK;
+}
+
+int nbody_sync(NbodyHandle* h) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+
+int nbody_set_profiling(NbodyHandle* h, int on) {
+    if (!h) return NBODY_ERR_INVALID;
+    h->profiling = on != 0;
+    return NBODY_OK;
+}
+
+int nbody_stats(NbodyHandle* h, NbodyStats* out) {
+    if (!h || !out) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = drain_events(h);
+    if (rc) return rc;
+    if (h->d_counters) {
+        HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->stats.interactions = h->h_counters[0];
+        h->stats.node_visits = h->h_counters[1];
+    }
+    *out = h->stats;
+    return NBODY_OK;
+}
+
+int nbody_reset_stats(NbodyHandle* h) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = drain_events(h);
+    if (rc) return rc;
+    uint64_t nodes = h->stats.tree_nodes;
+    h->stats = NbodyStats{};
+    h->stats.tree_nodes = nodes;
+    if (h->d_counters) {
+        HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return NBODY_OK;
+}
+
+int nbody_energy(NbodyHandle* h, double* kinetic, double* potential) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = sync_count(h);
+    if (rc) return rc;
+    const size_t n = h->n_local;
+    const size_t blocks = (n + 255) / 256;
+    double ke = 0.0, pe = 0.0;
+    if (blocks) {
+        if (blocks > h->energy_blocks) {
+            if (h->d_energy) (void)hipFree(h->d_energy);
+            h->d_energy = nullptr; h->energy_blocks = 0;
+            HIP_TRY(h, hipMalloc(&h->d_energy, blocks * 2 * sizeof(double)));
+            h->energy_blocks = blocks;
+        }
+        nbody::launch_energy(h->stream, h->sh, int(n), double(h->g_soft) * double(h->g_soft), h->d_energy);
+        HIP_TRY(h, hipGetLastError());
+        std::vector<double> part(blocks * 2);
+        HIP_TRY(h, hipMemcpyAsync(part.data(), h->d_energy, blocks * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (size_t b = 0; b < blocks; ++b) { ke += part[2 * b]; pe += part[2 * b + 1]; }
+    }
+    if (kinetic) *kinetic = ke;
+    if (potential) *potential = -0.5 * double(h->g) * pe;  // every unordered pair was met twice
+    return NBODY_OK;
+}
+
+int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* skip, size_t cap, size_t* n_nodes) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (h->cfg.method != NBODY_BARNES_HUT) return fail(h, NBODY_ERR_INVALID, "not a Barnes-Hut handle");
+    const size_t n = h->tree.n_nodes;
+    if (n_nodes) *n_nodes = n;
+    if (!com_mass && !width && !skip) return NBODY_OK;
+    if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "tree export buffer too small");
+    for (size_t i = 0; i < n; ++i) {
+        if (com_mass) { com_mass[4 * i] = h->tree.a[i].x; com_mass[4 * i + 1] = h->tree.a[i].y; com_mass[4 * i + 2] = h->tree.a[i].z; com_mass[4 * i + 3] = h->tree.a[i].m; }
+        if (width) width[i] = h->tree.b[i].w;
+        if (skip) skip[i] = h->tree.b[i].skip;
+    }
+    return NBODY_OK;
+}
+
+int nbody_comm_unique_id(void* id_bytes) {
+    if (!id_bytes) return NBODY_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) <= NBODY_COMM_ID_BYTES, "ncclUniqueId larger than NBODY_COMM_ID_BYTES");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, NBODY_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memset(id_bytes, 0, NBODY_COMM_ID_BYTES);
+    std::memcpy(id_bytes, &id, sizeof(id));
+    return NBODY_OK;
+}
+
+int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
+    if (!h || !id_bytes) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; h->comm_ready = false; }
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    NCCL_TRY(h, ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+    h->comm_ready = true;
+    return NBODY_OK;
+}
+
+int nbody_local_range(const NbodyHandle* h, size_t* first, size_t* count) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (first) *first = h->first_global;
+    if (count) *count = h->n_at_upload;
+    return NBODY_OK;
+}
+
+// Host-only entry (no device needed): the octree build alone, for tests of the host logic.
+// Arrays hold `cap` nodes (com_mass 4 floats per node); order holds n body ids.
+int nbody_host_build_tree(const float* pos4, size_t n, const float center[3], float width, int threads,
+                          float* com_mass, float* node_width, int32_t* skip, int32_t* leaf_body, int32_t* order,
+                          size_t cap, size_t* n_nodes) {
+    if ((!pos4 && n) || !center || !n_nodes) return NBODY_ERR_INVALID;
+    if (n > (1ull << 30)) return NBODY_ERR_INVALID;
+    nbody::WorkerPool pool(threads > 0 ? threads : 1);
+    nbody::HostTree tree;
+    int cnt = int(n);
+    nbody::build_octree(pos4, 1, int(n), &cnt, center, width, pool, tree);
+    if (tree.too_deep) return NBODY_ERR_TREE_DEPTH;
+    *n_nodes = tree.n_nodes;
+    if (!com_mass) return NBODY_OK;
+    if (tree.n_nodes > cap) return NBODY_ERR_CAPACITY;
+    for (size_t i = 0; i < tree.n_nodes; ++i) {
+        com_mass[4 * i] = tree.a[i].x; com_mass[4 * i + 1] = tree.a[i].y; com_mass[4 * i + 2] = tree.a[i].z; com_mass[4 * i + 3] = tree.a[i].m;
+        if (node_width) node_width[i] = tree.b[i].w;
+        if (skip) skip[i] = tree.b[i].skip;
+        if (leaf_body) leaf_body[i] = tree.b[i].body;
+    }
+    if (order) std::memcpy(order, tree.order, tree.n_order * sizeof(int32_t));
+    return NBODY_OK;
+}
+
+}  // extern "C"
