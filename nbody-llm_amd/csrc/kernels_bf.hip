@@ -46,9 +46,9 @@ __global__ __launch_bounds__(kStrictBlock) void k_bf_strict(const float4* __rest
                 if (t0 + j == self) continue;  // the reference never forms the i == j pair (:70-71)
                 const float4 pj = tile[j];
                 const float rx = pi.x - pj.x, ry = pi.y - pj.y, rz = pi.z - pj.z;  // :72
-                const float r_dist = __fsqrt_rn((rx * rx + ry * ry) + rz * rz + eps2);  // :73
+                const float r_dist = __builtin_sqrtf((rx * rx + ry * ry) + rz * rz + eps2);  // :73
                 const float r_cubed = r_dist * r_dist * r_dist;                    // :74
-                const float force = __fdiv_rn(g, r_cubed);                         // :77
+                const float force = (g / r_cubed);                         // :77
                 ax -= (rx * force) * pj.w;                                         // :78
                 ay -= (ry * force) * pj.w;
                 az -= (rz * force) * pj.w;
@@ -168,11 +168,14 @@ static void launch_fast_cfg(hipStream_t s, const Shard& sh, int n_upper, float g
                        sh.seg_count, sh.n_seg, sh.seg_cap, sh.my_seg, sh.acc, g, eps2);
 }
 
-int g_bf_fast_variant = 0;  // 0 = pick by size; test/bench hook (see nbody_api.cpp, NBODY_BF_VARIANT)
+}  // namespace nbody
+// 0 = pick by size; tuning/test hook (also set from the NBODY_BF_VARIANT environment variable)
+extern "C" int nbody_bf_fast_variant = 0;
+namespace nbody {
 
 void launch_bf_forces_fast(hipStream_t s, const Shard& sh, int n_upper, float g, float g_soft2) {
     if (n_upper <= 0) return;
-    int v = g_bf_fast_variant;
+    int v = nbody_bf_fast_variant;
     if (v == 0) {
         // enough workgroups to cover the 256 CUs, then as many bodies per lane as that allows
         if (n_upper >= 256 * 256) v = 4;

@@ -48,9 +48,9 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const float4* __restrict
                     const float rinv = __builtin_amdgcn_rsqf(r2 + eps2);
                     k = (g * A.w) * ((rinv * rinv) * rinv);
                 } else {
-                    const float r_dist = __fsqrt_rn(r2 + eps2);                 // :193
+                    const float r_dist = __builtin_sqrtf(r2 + eps2);                 // :193
                     const float r_cubed = r_dist * r_dist * r_dist;             // :194
-                    k = __fdiv_rn(g * A.w, r_cubed);                            // :195
+                    k = ((g * A.w) / r_cubed);                            // :195
                 }
                 ax += rx * k; ay += ry * k; az += rz * k;
                 ++n_acc;

@@ -21,7 +21,7 @@
 #include <thread>
 #include <vector>
 
-namespace nbody { extern int g_bf_fast_variant; }
+extern "C" int nbody_bf_fast_variant;
 
 using nbody::BoundsF;
 using nbody::Shard;
@@ -393,7 +393,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
-    if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody::g_bf_fast_variant = std::atoi(v);
+    if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
     *out = h;
     return NBODY_OK;
 }

@@ -1,0 +1,305 @@
+"""Parity of the brute-force HIP path (K1/K2/K3/K4 through the C ABI) against the oracle.
+strict math: bit-exact.  fast math: acceleration error <= 1e-5 of the largest acceleration
+(north_star: "stated fp32 tolerance"), positions after 100 steps <= 1e-4 length units."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+BOX = ((0.0, 0.0, 0.0), 64.0)
+FIELDS = ("position", "velocity", "acceleration", "mass")
+
+
+def settings(nb, **kw):
+    d = dict(g=1.0, g_soft=0.0, dt=1e-3, theta2=0.5)
+    d.update(kw)
+    return d, nb.Settings(**d)
+
+
+def run_gpu(nb, ics, st, steps, math_mode, box=BOX):
+    with nb.Simulation(ics, *box, method=nb.BRUTE_FORCE, math_mode=math_mode) as sim:
+        sim.settings = st
+        sim.init()
+        sim.steps(steps)
+        out = sim.get_points()
+        return out, sim.elapsed()
+
+
+def run_oracle(orc, ics, sd, steps, box=BOX):
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(steps):
+        ref = orc.bf_step_by(ref, sd, box[0], box[1], sd["dt"])
+    return ref
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 1024, 1025, 3000])
+def test_strict_bit_exact_ragged_sizes(gpu, orc, n):
+    nb = gpu
+    sd, st = settings(nb)
+    ics = nb.plummer(n, seed=n)
+    got, _ = run_gpu(nb, ics, st, 2, nb.STRICT)
+    ref = run_oracle(orc, ics, sd, 2)
+    assert len(got) == len(ref) == n
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+
+
+def test_strict_bit_exact_config0_1024_bodies_20_steps(gpu, orc):
+    """BASELINE configs[0]: 1 024 bodies, brute force, reference defaults (g_soft = 0)."""
+    nb = gpu
+    sd, st = settings(nb)
+    ics = nb.plummer(1024)
+    got, t = run_gpu(nb, ics, st, 20, nb.STRICT)
+    ref = run_oracle(orc, ics, sd, 20)
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    assert t == pytest.approx(20e-3, rel=1e-5)
+
+
+def test_strict_bit_exact_softened_g_and_negative_dt(gpu, orc):
+    """settings_mut between steps, including the visualiser's rewind step_by(-dt) (vis.rs:236-251)."""
+    nb = gpu
+    ics = nb.plummer(500, seed=3)
+    ref = ics.copy().astype(orc.P32)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.STRICT) as sim:
+        sim.init()
+        for g, eps, dt in [(1.0, 0.0, 1e-3), (2.5, 0.05, 4e-3), (0.7, 0.2, -2e-3), (1.0, 0.0, -1e-3)]:
+            sd, st = settings(nb, g=g, g_soft=eps, dt=dt)
+            sim.settings = st
+            sim.step()
+            ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], np.float32(dt))
+        got = sim.get_points()
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+
+
+def test_update_forces_alone_and_empty(gpu, orc):
+    nb = gpu
+    sd, st = settings(nb, g_soft=0.1)
+    ics = nb.plummer(300, seed=8)
+    ref = ics.copy().astype(orc.P32)
+    orc.bf_update_forces(ref, sd)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+    assert np.array_equal(got["acceleration"], ref["acceleration"])
+    assert np.array_equal(got["position"], ics["position"])
+    with nb.Simulation(np.zeros(0, nb.PARTICLE_DTYPE), *BOX, capacity=8) as sim:
+        sim.steps(3)
+        assert len(sim) == 0 and len(sim.get_points()) == 0
+
+
+@pytest.mark.parametrize("math_mode", ["STRICT", "FAST"])
+def test_bodies_leaving_the_box_are_dropped_in_order(gpu, orc, math_mode):
+    """Vec::retain between the half drift and the forces (brute_force.rs:86): a tight box so that
+    bodies escape over many steps; counts and survivor order must match the oracle exactly."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 1.5)
+    sd, st = settings(nb, dt=2e-2, g_soft=0.05)
+    ics = nb.plummer(2000, seed=5)
+    ref = ics.copy().astype(orc.P32)
+    counts = []
+    with nb.Simulation(ics, *box, method=nb.BRUTE_FORCE, math_mode=getattr(nb, math_mode)) as sim:
+        sim.settings = st
+        sim.init()
+        for k in range(12):
+            sim.step()
+            ref = orc.bf_step_by(ref, sd, box[0], box[1], sd["dt"])
+            if k % 4 == 3:
+                counts.append((len(sim), len(ref)))
+        got = sim.get_points()
+    assert all(a == b for a, b in counts), counts
+    assert len(ref) < 2000 * 0.9, "the case must actually drop bodies"
+    assert np.array_equal(got["mass"], ref["mass"])
+    if math_mode == "STRICT":
+        for f in FIELDS:
+            assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    else:
+        assert rel_err(got["position"], ref["position"]) < 1e-5
+
+
+def test_escape_on_the_first_steps_nan_and_boundary(gpu, orc):
+    nb = gpu
+    ics = nb.plummer(130, seed=2)
+    ics["velocity"][:] = 0
+    ics["position"][5] = [32.0, 0, 0]         # exactly on the wall: kept (inclusive)
+    ics["position"][6] = [32.000004, 0, 0]    # just outside
+    ics["position"][64] = [0, np.nan, 0]      # NaN: dropped
+    ics["position"][129] = [0, 0, -40]
+    sd, st = settings(nb, g_soft=0.5)
+    got, _ = run_gpu(nb, ics, st, 1, nb.STRICT)
+    ref = run_oracle(orc, ics, sd, 1)
+    assert len(got) == len(ref) == 127
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+
+
+def test_add_and_swap_remove(gpu, orc):
+    """add_point = push, remove_point = swap_remove (brute_force.rs:92-98)."""
+    nb = gpu
+    ics = nb.plummer(100, seed=12)
+    extra = nb.plummer(3, seed=13)
+    sd, st = settings(nb, g_soft=0.01)
+    host = list(ics.copy())
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.STRICT, capacity=102) as sim:
+        sim.settings = st
+        sim.add_point(extra[0]); host.append(extra[0])
+        sim.remove_point(10); host[10] = host[-1]; host.pop()
+        sim.remove_point(len(host) - 1); host.pop()
+        sim.add_point(extra[1]); host.append(extra[1])
+        sim.add_point(extra[2]); host.append(extra[2])
+        assert len(sim) == len(host) == 101
+        with pytest.raises(nb.NbodyError) as e:
+            sim.remove_point(500)
+        assert e.value.code == nb.NBODY_ERR_INVALID
+        sim.add_point(extra[0]); host.append(extra[0])
+        with pytest.raises(nb.NbodyError) as e:
+            sim.add_point(extra[0])
+        assert e.value.code == nb.NBODY_ERR_CAPACITY
+        sim.steps(2)
+        got = sim.get_points()
+    ref = np.array(host, dtype=nb.PARTICLE_DTYPE).astype(orc.P32)
+    for _ in range(2):
+        ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], sd["dt"])
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+
+
+def test_clone_is_independent(gpu, orc):
+    """`Clone` (shared.rs:80): the visualiser's reset keeps a pristine copy (vis.rs:217-220)."""
+    nb = gpu
+    sd, st = settings(nb)
+    ics = nb.plummer(256, seed=21)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.steps(2)
+        with sim.clone() as twin:
+            assert twin.elapsed() == sim.elapsed() and twin.settings == sim.settings
+            sim.steps(3)
+            mid = twin.get_points()
+            twin.steps(3)
+            a, b = sim.get_points(), twin.get_points()
+    ref2 = run_oracle(orc, ics, sd, 2)
+    assert np.array_equal(mid["position"], ref2["position"])
+    for f in FIELDS:
+        assert np.array_equal(a[f], b[f])
+
+
+@pytest.mark.parametrize("n,eps", [(1024, 0.0), (3000, 0.0), (4097, 1e-2), (20000, 1e-2)])
+def test_fast_accelerations_within_tolerance(gpu, orc, n, eps):
+    """fast kernel (v_rsq_f32 + FMA + wave-split partner range) vs the f32 oracle: <= 1e-5 of the
+    largest acceleration; the f64 oracle on the same inputs bounds what f32 itself can do."""
+    nb = gpu
+    sd, st = settings(nb, g_soft=eps)
+    ics = nb.plummer(n, seed=n)
+    ref = ics.copy().astype(orc.P32)
+    orc.bf_update_forces_rows(ref, sd, threads=8)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    # per-body relative error too (bodies in the sparse halo feel tiny accelerations)
+    num = np.linalg.norm(got["acceleration"].astype(np.float64) - ref["acceleration"], axis=1)
+    den = np.linalg.norm(ref["acceleration"].astype(np.float64), axis=1)
+    assert np.max(num / den) < 1e-4
+
+
+def test_fast_every_kernel_variant_agrees(gpu, orc):
+    """All (bodies-per-lane, waves) instantiations of the fast kernel against the oracle, on a size
+    that exercises partial tiles and the self-pair (diagonal) slices."""
+    import ctypes
+    nb = gpu
+    sd, st = settings(nb)
+    n = 5000
+    ics = nb.plummer(n, seed=77)
+    ref = ics.copy().astype(orc.P32)
+    orc.bf_update_forces_rows(ref, sd, threads=8)
+    variant = ctypes.c_int.in_dll(nb.lib, "nbody_bf_fast_variant")
+    try:
+        for v in (1, 2, 4, 8, 24, 42, 116):
+            variant.value = v
+            with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
+                sim.settings = st
+                sim.update_forces()
+                got = sim.get_points()
+            assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5, v
+    finally:
+        variant.value = 0
+
+
+def test_fast_trajectory_100_steps(gpu, orc):
+    nb = gpu
+    sd, st = settings(nb, g_soft=1e-2)
+    ics = nb.plummer(2048, seed=1)
+    got, _ = run_gpu(nb, ics, st, 100, nb.FAST)
+    ref = run_oracle(orc, ics, sd, 100)
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-4
+    assert np.abs(got["velocity"].astype(np.float64) - ref["velocity"]).max() < 1e-3
+
+
+def test_energy_diagnostic_matches_oracle(gpu, orc):
+    nb = gpu
+    ics = nb.plummer(3000, seed=6)
+    with nb.Simulation(ics, *BOX) as sim:
+        sim.settings = nb.Settings(g=1.5, g_soft=0.02)
+        ke, pe = sim.energy()
+    # the handle stores settings as f32 (SimulationSettings<f32>): give the oracle the same values
+    rke, rpe = orc.energy(ics.astype(orc.P32), float(np.float32(1.5)), float(np.float32(0.02)))
+    assert ke == pytest.approx(rke, rel=1e-12) and pe == pytest.approx(rpe, rel=1e-12)
+
+
+# ------------------------------------------------------------------ BASELINE.json full size
+def test_full_size_65536_properties_and_sampled_rows(gpu, orc):
+    """configs[1]: 65 536 bodies.  The oracle cannot finish all 4.3e9 pairs in seconds, so: (a) a
+    sample of rows against the f32 oracle over ALL partners: bit-exact for strict, <= 1e-5 for
+    fast; (b) the same rows in f64: the fast kernel (8 partial sums per body) is no further from the
+    exact sum than the reference's own f32 sequential sum is; (c) fast vs strict over all bodies
+    <= 3e-5 (a 65 535-term f32 sequential sum itself carries ~1e-5 of rounding); (d) total
+    momentum of the force field ~ 0."""
+    nb = gpu
+    n = 65536
+    sd, st = settings(nb, g_soft=1e-2)
+    ics = nb.plummer(n)
+    out = {}
+    for mode in ("STRICT", "FAST"):
+        with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=getattr(nb, mode)) as sim:
+            sim.settings = st
+            sim.update_forces()
+            out[mode] = sim.get_points()["acceleration"]
+    ref = ics.copy().astype(orc.P32)
+    ref64 = orc.to_f64(ics)
+    sd64 = dict(sd, g_soft=float(np.float32(sd["g_soft"])))
+    rows = [(0, 64), (4090, 4110), (32768 - 8, 32768 + 8), (65536 - 64, 65536)]
+    for lo, hi in rows:
+        orc.bf_update_forces_range(ref, sd, lo, hi, threads=8)
+        orc.bf_update_forces_range(ref64, sd64, lo, hi, threads=8)
+        assert np.array_equal(out["STRICT"][lo:hi].view(np.uint32), ref["acceleration"][lo:hi].view(np.uint32))
+        assert rel_err(out["FAST"][lo:hi], ref["acceleration"][lo:hi]) < 1e-5
+        exact = ref64["acceleration"][lo:hi]
+        e_fast, e_ref = rel_err(out["FAST"][lo:hi], exact), rel_err(ref["acceleration"][lo:hi], exact)
+        assert e_fast < 1e-5 and e_fast <= max(2 * e_ref, 2e-6)
+    assert rel_err(out["FAST"], out["STRICT"]) < 3e-5
+    m = ics["mass"].astype(np.float64)[:, None]
+    for mode in out:
+        p = (out[mode].astype(np.float64) * m).sum(0)
+        assert np.abs(p).max() < 1e-6 * np.abs(out[mode].astype(np.float64) * m).sum()
+
+
+def test_full_size_65536_energy_drift_matches_small_step_expectation(gpu):
+    """Energy of the f32 fast path over 50 steps at N = 65 536, dt = 1e-3, eps = 1e-2 (f64 energy
+    evaluated on the device): relative drift stays below 1e-5."""
+    nb = gpu
+    ics = nb.plummer(65536)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
+        sim.settings = nb.Settings(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
+        ke0, pe0 = sim.energy()
+        sim.steps(50)
+        ke1, pe1 = sim.energy()
+        assert len(sim) == 65536
+    e0, e1 = ke0 + pe0, ke1 + pe1
+    assert e0 == pytest.approx(-0.25, abs=0.01)
+    assert abs((e1 - e0) / e0) < 1e-5

@@ -1,0 +1,190 @@
+"""Parity of the Barnes-Hut HIP path (host octree + K5 walk through the C ABI) against the oracle.
+Index/integer work is bit-exact: the octree (cells, pre-order, skip links, centre-of-mass bits)
+and the accepted/visited node counts.  Accelerations: the device adds accepted monopoles into one
+running sum while the reference nests the sums per tree level, so they agree to rounding:
+<= 1e-5 of the largest acceleration."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+BOX = ((0.0, 0.0, 0.0), 64.0)
+
+
+def sd_st(nb, **kw):
+    d = dict(g=1.0, g_soft=0.0, dt=1e-3, theta2=0.5)
+    d.update(kw)
+    return d, nb.Settings(**d)
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 300, 1024, 5000])
+@pytest.mark.parametrize("theta2", [0.25, 0.5, 1.0])
+def test_update_forces_tree_counts_and_accelerations(gpu, orc, n, theta2):
+    nb = gpu
+    sd, st = sd_st(nb, theta2=theta2, g_soft=0.02)
+    ics = nb.plummer(n, seed=10 + n)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4)
+    rt = orc.bh_build_tree(ics.astype(orc.P32), BOX[0], BOX[1])
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+        t = sim.tree()
+    assert np.array_equal(t["com_mass"].view(np.uint32), rt["com_mass"].view(np.uint32))
+    assert np.array_equal(t["width"], rt["width"]) and np.array_equal(t["skip"], rt["skip"])
+    assert (s.interactions, s.node_visits, s.tree_nodes) == (acc_n, vis_n, len(rt["width"]))
+    if np.abs(ref["acceleration"]).max() > 0:
+        assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    else:
+        assert not got["acceleration"].any()
+    assert np.array_equal(got["position"], ics["position"])
+
+
+@pytest.mark.parametrize("theta2,expect", [(3.0, (2, 4)), (1.0, (2, 6)), (0.25, (0, 6))])
+def test_leaf_drop_cases(gpu, orc, theta2, expect):
+    """The two-body cases of tests/test_oracle_pins.py on the device: root accepted with the
+    body's own mass inside; other leaf accepted; other leaf rejected -> exactly zero."""
+    nb = gpu
+    ics = np.zeros(2, nb.PARTICLE_DTYPE)
+    ics["position"] = [[-1, -1, -1], [1, 1, 1]]
+    ics["mass"] = [1, 3]
+    sd, st = sd_st(nb, theta2=theta2)
+    ref = ics.copy().astype(orc.P32)
+    orc.bh_update_forces(ref, sd, (0, 0, 0), 4.0, 1)
+    with nb.Simulation(ics, (0, 0, 0), 4.0, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+    assert (s.interactions, s.node_visits) == expect
+    # one accepted node per body at most: no summation-order freedom, so bit-exact
+    assert np.array_equal(got["acceleration"].view(np.uint32), ref["acceleration"].view(np.uint32))
+
+
+def test_steps_follow_the_oracle(gpu, orc):
+    """10 x step_by on 2 000 bodies: counts per step equal, trajectories to rounding."""
+    nb = gpu
+    sd, st = sd_st(nb, theta2=0.25, g_soft=0.01)
+    ics = nb.plummer(2000, seed=31)
+    ref = ics.copy().astype(orc.P32)
+    tot_a = tot_v = 0
+    for _ in range(10):
+        ref, a, v = orc.bh_step_by(ref, sd, BOX[0], BOX[1], sd["dt"], threads=4)
+        tot_a += a
+        tot_v += v
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.init()
+        sim.steps(10)
+        got = sim.get_points()
+        s = sim.stats()
+        assert sim.elapsed() == pytest.approx(10e-3, rel=1e-5)
+    assert (s.interactions, s.node_visits, s.steps) == (tot_a, tot_v, 10)
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
+    assert rel_err(got["velocity"], ref["velocity"]) < 1e-5
+
+
+def test_fast_math_walk_same_nodes(gpu, orc):
+    """fast math changes only the monopole evaluation (v_rsq_f32); the opening tests are the same."""
+    nb = gpu
+    sd, st = sd_st(nb, theta2=0.25, g_soft=0.01)
+    ics = nb.plummer(3000, seed=32)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+
+
+def test_retain_in_a_tight_box(gpu, orc):
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 2.0)
+    sd, st = sd_st(nb, theta2=0.5, g_soft=0.05, dt=2e-2)
+    ics = nb.plummer(1500, seed=33)
+    ref = ics.copy().astype(orc.P32)
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        for _ in range(8):
+            sim.step()
+            ref, _, _ = orc.bh_step_by(ref, sd, box[0], box[1], sd["dt"], threads=2)
+            assert len(sim) == len(ref)
+        got = sim.get_points()
+    assert len(ref) < 1400
+    assert np.array_equal(got["mass"], ref["mass"])
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-5
+
+
+def test_reference_workload_disc(gpu, orc):
+    """The reference's own configuration (src/main.rs:97-105): disc ICs, box 10, dt=3e-2,
+    g_soft=0.02, theta2=1.0."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 10.0)
+    sd, st = sd_st(nb, theta2=1.0, g_soft=0.02, dt=3e-2)
+    ics = nb.disc(4000, seed=2)
+    ref = ics.copy().astype(orc.P32)
+    tot = 0
+    for _ in range(5):
+        ref, a, _ = orc.bh_step_by(ref, sd, box[0], box[1], sd["dt"], threads=4)
+        tot += a
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.STRICT, host_threads=4) as sim:
+        sim.settings = st
+        sim.init()
+        sim.steps(5)
+        got = sim.get_points()
+        s = sim.stats()
+    assert len(got) == len(ref) and s.interactions == tot
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-5
+
+
+def test_coincident_bodies_report_tree_depth(gpu):
+    nb = gpu
+    ics = np.zeros(3, nb.PARTICLE_DTYPE)
+    ics["position"] = [[0.3, 0.3, 0.3], [0.3, 0.3, 0.3], [1, 1, 1]]
+    ics["mass"] = 1
+    with nb.Simulation(ics, (0, 0, 0), 4.0, method=nb.BARNES_HUT) as sim:
+        with pytest.raises(nb.NbodyError) as e:
+            sim.update_forces()
+        assert e.value.code == nb.NBODY_ERR_TREE_DEPTH
+
+
+def test_clone_drops_tree_and_keeps_state(gpu, orc):
+    nb = gpu
+    sd, st = sd_st(nb, theta2=0.25)
+    ics = nb.plummer(500, seed=34)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT) as sim:
+        sim.settings = st
+        sim.steps(2)
+        with sim.clone() as twin:
+            sim.steps(2)
+            twin.steps(2)
+            assert np.array_equal(sim.get_points(), twin.get_points())
+
+
+# ------------------------------------------------------------------ BASELINE.json full size
+def test_full_size_65536_theta_half(gpu, orc):
+    """configs[2]: 65 536 bodies, theta = 0.5 (theta2 = 0.25).  The threaded oracle finishes one
+    force pass in seconds: tree bit-exact, node counts equal, accelerations to rounding."""
+    nb = gpu
+    sd, st = sd_st(nb, theta2=0.25, g_soft=1e-2)
+    ics = nb.plummer(65536)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=16)
+    rt = orc.bh_build_tree(ics.astype(orc.P32), BOX[0], BOX[1])
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+        t = sim.tree()
+    assert np.array_equal(t["com_mass"].view(np.uint32), rt["com_mass"].view(np.uint32))
+    assert np.array_equal(t["skip"], rt["skip"])
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
