@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 namespace nbody {
 
@@ -42,6 +43,21 @@ void launch_kick_drift(hipStream_t s, const Shard& sh, int n_upper, float dt);
 // K2: BruteForceSimulation::update_forces (brute_force.rs:64-82)
 void launch_bf_forces_strict(hipStream_t s, const Shard& sh, int n_upper, float g, float g_soft2);
 void launch_bf_forces_fast(hipStream_t s, const Shard& sh, int n_upper, float g, float g_soft2);
+
+// K2, symmetric form (every unordered pair once, both bodies updated): kernels_bf_sym.hip
+struct SymPlan {
+    int ipt = 8;          // resident bodies per lane
+    int A = 0;            // resident sets of 64*ipt bodies
+    int K = 0;            // waves per resident set
+    int wpb = 16;         // waves per workgroup (16: one workgroup per CU, 12: two)
+    int sym_sets = 0;     // sets met symmetrically = ceil(A/2) - 1
+    int n_planes = 0;     // partial-sum planes
+    size_t n_pad = 0;     // bodies per plane (A * 64 * ipt)
+    std::vector<int> bounds;  // K+1 cut points of a set's chunk sequence
+};
+SymPlan make_sym_plan(int n_upper);
+void launch_bf_forces_sym(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
+                          int n_upper, float g, float g_soft2);
 
 // K5: BarnesHutSimulation::calc_force (barnes_hut.rs:185-203) over a linearised octree
 struct TreeDev {

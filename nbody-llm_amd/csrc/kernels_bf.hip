@@ -188,6 +188,7 @@ void launch_bf_forces_fast(hipStream_t s, const Shard& sh, int n_upper, float g,
         case 42: launch_fast_cfg<4, 4, 2048>(s, sh, n_upper, g, g_soft2); break;
         case 24: launch_fast_cfg<2, 4, 2048>(s, sh, n_upper, g, g_soft2); break;
         case 8: launch_fast_cfg<8, 8, 4096>(s, sh, n_upper, g, g_soft2); break;
+        case 416: launch_fast_cfg<4, 16, 4096>(s, sh, n_upper, g, g_soft2); break;
         case 116: launch_fast_cfg<1, 16, 2048>(s, sh, n_upper, g, g_soft2); break;
         default: launch_fast_cfg<1, 8, 2048>(s, sh, n_upper, g, g_soft2); break;
     }

@@ -1,0 +1,313 @@
+// kernels_bf_sym.hip -- K2 "symmetric": all-pairs gravity that evaluates every unordered pair
+// ONCE and applies it to both bodies, as BruteForceSimulation::update_forces does on the CPU
+// (src/manual/brute_force.rs:70-81: a_i -= r f m_j ; a_j += r f m_i), restated for 64-lane waves.
+//
+// Work unit = one wave; no LDS memory, no barrier:
+//   * the wave keeps a RESIDENT SET of 64*IPT bodies in registers (lane l: bodies q*64 + l);
+//   * TRAVELLING CHUNKS of 64 bodies (one per lane, with their own accumulators) are rotated
+//     through the lanes one lane per step with ds_bpermute_b32 (the LDS crossbar, which runs beside
+//     the VALU; a DPP wave_ror:1 rotate costs ~10 VALU cycles per register in this stream); after
+//     64 steps every lane has met every travelling body and the chunk is back in its home lanes;
+//   * each step evaluates IPT pairs per lane and updates both sides: 16 VALU + 1 v_rsq_f32 per
+//     unordered pair (= 2 directed interactions), written stage by stage over the IPT pairs so
+//     that no instruction waits for its predecessor.
+// Measured on MI355X (tools/sym_cycles.py, in-kernel stamps): 388 SIMD cycles per 8-pair step at
+// 2.37 GHz = 128 x 2.2 (fp32 VALU) + 8 x 13 (v_rsq_f32): the kernel is fp32-issue bound.
+//
+// Decomposition (balanced by construction): with A resident sets, set a meets the chunks of sets
+// a+1 .. a+ceil(A/2)-1 (cyclic) symmetrically (k_bf_sym); the pairs inside a set and, for even
+// A, with the opposite set are evaluated one-sidedly by k_bf_sym_rest (~3 % of the evaluations).
+// The chunk sequence of a set is cut into K equal parts, one per wave.
+// Partial sums go to "planes" of float4[n_pad]: plane d-1 receives the travelling-side sums of
+// set distance d, plane sym_sets+p the resident-side sums of slice p of each set, the last
+// plane k_bf_sym_rest's; every plane entry is written exactly once per launch, so the reduction
+// (k_bf_sym_reduce) adds the planes in a fixed order: deterministic, no atomics.
+//
+// fast math only (v_rsq_f32 + FMA; summation order differs from the reference): tolerance 1e-5.
+#include "kernels.h"
+
+namespace nbody {
+
+namespace {
+
+// rotate by one lane through the LDS crossbar: lane l receives lane (l-1)&63's value.  No LDS memory
+// is touched and no VALU slot is spent; the result arrives ~60+ cycles later, behind other work.
+__device__ __forceinline__ float rotl(float v, int src_lane_x4) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_x4, __float_as_int(v)));
+}
+
+#define PAD_POS 1.0e15f  // zero-mass padding bodies sit far away: they exert and (after masking) receive nothing
+
+__device__ unsigned long long nbody_sym_stamps[3 * 8192];  // diagnostic builds only (DBG & 4)
+
+// One rotation step: IPT unordered pairs per lane, written stage by stage over all IPT pairs so
+// that every instruction's inputs were produced at least IPT instructions earlier (the compiler's
+// own schedule chains dependent fma -> rsq -> mul -> fma back to back and issues at ~4 cycles per
+// instruction instead of ~2.3; sched_barrier keeps the stages in this order).
+template <int IPT, int DBG = 0>
+__device__ __forceinline__ void pair_evals(const float (&xi)[IPT], const float (&yi)[IPT], const float (&zi)[IPT],
+                                           const float (&mi)[IPT], float (&axi)[IPT], float (&ayi)[IPT],
+                                           float (&azi)[IPT], float xj, float yj, float zj, float mj, float& axj,
+                                           float& ayj, float& azj, float eps2) {
+    float dx[IPT], dy[IPT], dz[IPT], r[IPT], sj[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) dx[q] = xj - xi[q];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) dy[q] = yj - yi[q];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) dz[q] = zj - zi[q];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) r[q] = __builtin_fmaf(dx[q], dx[q], eps2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) r[q] = __builtin_fmaf(dy[q], dy[q], r[q]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) r[q] = __builtin_fmaf(dz[q], dz[q], r[q]);
+    __builtin_amdgcn_sched_barrier(0);
+    // v_rsq_f32 costs ~8 cycles back to back but ~13-15 in this mixed stream (measured in place by
+    // swapping it for a multiply); raising the wave's priority around the burst does not help
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        if (DBG & 2) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(r[q]));  // timing experiment: no transcendental
+        else r[q] = __builtin_amdgcn_rsqf(r[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) sj[q] = r[q] * r[q];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) r[q] = sj[q] * r[q];   // rinv^3
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) sj[q] = mj * r[q];     // what body j does to body i
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) r[q] = mi[q] * r[q];   // what body i does to body j
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        axi[q] = __builtin_fmaf(dx[q], sj[q], axi[q]);
+        axj = __builtin_fmaf(-dx[q], r[q], axj);
+        ayi[q] = __builtin_fmaf(dy[q], sj[q], ayi[q]);
+        ayj = __builtin_fmaf(-dy[q], r[q], ayj);
+        azi[q] = __builtin_fmaf(dz[q], sj[q], azi[q]);
+        azj = __builtin_fmaf(-dz[q], r[q], azj);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace
+
+// WPB waves per workgroup, sized so that exactly one (WPB = 16) or two (WPB = 12) workgroups fit a
+// CU: the dispatcher then has no choice but to spread the grid evenly.  With small workgroups it
+// packs some CUs to their register limit and leaves others nearly empty, and the kernel lasts as
+// long as the fullest SIMD (measured with in-kernel stamps: wave lifetimes 560-960 us, +55 %).
+template <int IPT, int WPB, int DBG = 0>
+__global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ pos, const int* __restrict__ count,
+                                                     int A, int K, const int* __restrict__ bounds, int sym_sets,
+                                                     float4* __restrict__ planes, size_t plane_stride, float eps2) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * WPB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // global wave index
+    if (gw >= A * K) return;
+    const int a = gw / K;                        // resident set
+    const int part = gw - a * K;                 // this wave's slice of the set's chunk sequence
+    const int n = *count;
+    const int Cn = A * IPT;                      // chunks in the padded body array
+    const int k0 = bounds[part], k1 = bounds[part + 1];
+    const int src_lane = ((lane + 63) & 63) * 4;  // ds_bpermute address: take from the lane below
+    const int src_lane2 = ((lane + 62) & 63) * 4; // two lanes below
+    // eps2 lives in a VGPR: with an SGPR operand the compiler cannot tell inside the loop whether the
+    // kernel-argument load has landed and drains ALL pending LDS traffic (lgkmcnt(0)) every step
+    float eps2v = eps2;
+    asm volatile("" : "+v"(eps2v));
+
+    float xi[IPT], yi[IPT], zi[IPT], mi[IPT], axi[IPT], ayi[IPT], azi[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        const int i = (a * IPT + q) * 64 + lane;
+        const float4 p = (i < n) ? pos[i] : make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
+        xi[q] = p.x; yi[q] = p.y; zi[q] = p.z; mi[q] = p.w;
+        axi[q] = ayi[q] = azi[q] = 0.f;
+    }
+
+    // chunk k of this set's sequence: the chunks of the next sym_sets sets, in cyclic order
+    auto chunk_of = [&](int k) {
+        int c = (a + 1) * IPT + k;
+        if (c >= Cn) c -= Cn;
+        return c;
+    };
+    auto load_chunk = [&](int k) {
+        const int j = chunk_of(k) * 64 + lane;
+        return (j < n) ? pos[j] : make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
+    };
+
+    unsigned long long t_beg = 0, r_beg = 0;
+    if (DBG & 4) { t_beg = __builtin_amdgcn_s_memtime(); r_beg = __builtin_amdgcn_s_memrealtime(); }
+    float4 nxt = (k0 < k1) ? load_chunk(k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = k0; k < k1; ++k) {
+        float xj = nxt.x, yj = nxt.y, zj = nxt.z, mj = nxt.w;
+        float axj = 0.f, ayj = 0.f, azj = 0.f;
+        if (k + 1 < k1) nxt = load_chunk(k + 1);
+        // The SIMD arbitrates VALU issue by priority, then age: at equal priority the oldest wave
+        // runs at full speed, the youngest gets the leftovers, and once the old waves are done the
+        // last one runs alone at half the SIMD's rate.  Priority = quarter of the work still to
+        // do, so the waves of a SIMD advance together and finish together.
+        switch ((4 * (k1 - k) - 1) / (k1 - k0)) {
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+        }
+        // positions are rotated two steps ahead (they do not change while the chunk travels), so the
+        // crossbar latency never sits between a rotate and its first use
+        float x1 = rotl(xj, src_lane), y1 = rotl(yj, src_lane), z1 = rotl(zj, src_lane), m1 = rotl(mj, src_lane);
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+            const float x2 = rotl(xj, src_lane2), y2 = rotl(yj, src_lane2), z2 = rotl(zj, src_lane2), m2 = rotl(mj, src_lane2);
+            pair_evals<IPT, DBG>(xi, yi, zi, mi, axi, ayi, azi, xj, yj, zj, mj, axj, ayj, azj, eps2v);
+            // the accumulators follow their body; they are next needed at the END of the next step
+            axj = rotl(axj, src_lane); ayj = rotl(ayj, src_lane); azj = rotl(azj, src_lane);
+            xj = x1; yj = y1; zj = z1; mj = m1;
+            x1 = x2; y1 = y2; z1 = z2; m1 = m2;
+        }
+        const int d = k / IPT + 1;  // set distance 1..sym_sets
+        planes[size_t(d - 1) * plane_stride + size_t(chunk_of(k)) * 64 + lane] = make_float4(axj, ayj, azj, 0.f);
+    }
+
+    if (DBG & 4) {  // diagnostic build: shader cycles and 100 MHz ticks of this wave's chunk loop, into a
+                    // buffer of their own that nothing else reads
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && gw < 8192) {
+            nbody_sym_stamps[gw * 3 + 0] = t_end - t_beg;
+            nbody_sym_stamps[gw * 3 + 1] = r_end - r_beg;
+            // chunk count | HW_ID (wave slot, SIMD, CU, SE) | XCC_ID: where the dispatcher put this wave
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+            nbody_sym_stamps[gw * 3 + 2] = (unsigned long long)(k1 - k0) | ((unsigned long long)hw << 16) | ((unsigned long long)(xcc & 0xF) << 48);
+        }
+    }
+    // resident side: one plane per slice index
+    float4* __restrict__ out = planes + size_t(sym_sets + part) * plane_stride;
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) out[size_t(a * IPT + q) * 64 + lane] = make_float4(axi[q], ayi[q], azi[q], 0.f);
+}
+
+// The pairs the rotation scheme leaves out: every body against its own set (self excluded) and,
+// when A is even, against the opposite set -- one-sided, since the opposite set does the same for
+// ours.  64 bodies per workgroup, the 1 or 2 windows of 64*IPT partners split over 8 waves whose
+// partner index is wave-uniform (scalar loads); ~3 % of the pair evaluations.
+template <int IPT>
+__global__ __launch_bounds__(512) void k_bf_sym_rest(const float4* __restrict__ pos, const int* __restrict__ count,
+                                                     int A, float4* __restrict__ plane, float eps2) {
+    constexpr int SET = 64 * IPT, WAVES = 8, SLICE = SET / WAVES;
+    __shared__ float red[WAVES - 1][3][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = *count;
+    const int i = blockIdx.x * 64 + lane;
+    const int a = (blockIdx.x * 64) / SET;
+    const float4 pi = (i < n) ? pos[i] : make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const int n_win = (A % 2 == 0 && A > 1) ? 2 : 1;
+    for (int w = 0; w < n_win; ++w) {
+        int set = (w == 0) ? a : a + A / 2;
+        if (set >= A) set -= A;
+        const int j0 = set * SET + wv * SLICE;
+        const int j1 = min(n, j0 + SLICE);
+        for (int j = j0; j < j1; ++j) {
+            const float4 pj = pos[j];  // wave-uniform address
+            const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
+            const float rinv = __builtin_amdgcn_rsqf(r2);
+            float sj = pj.w * ((rinv * rinv) * rinv);
+            sj = (j == i) ? 0.f : sj;
+            ax = __builtin_fmaf(dx, sj, ax);
+            ay = __builtin_fmaf(dy, sj, ay);
+            az = __builtin_fmaf(dz, sj, az);
+        }
+    }
+    if (wv > 0) { red[wv - 1][0][lane] = ax; red[wv - 1][1][lane] = ay; red[wv - 1][2][lane] = az; }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int w = 0; w < WAVES - 1; ++w) { ax += red[w][0][lane]; ay += red[w][1][lane]; az += red[w][2][lane]; }
+        plane[i] = make_float4(ax, ay, az, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict__ planes, int n_planes,
+                                                       size_t plane_stride, const int* __restrict__ count, float g,
+                                                       float4* __restrict__ acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *count) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int p = 0; p < n_planes; ++p) {
+        const float4 v = planes[size_t(p) * plane_stride + i];
+        sx += v.x; sy += v.y; sz += v.z;
+    }
+    acc[i] = make_float4(g * sx, g * sy, g * sz, 0.f);
+}
+
+}  // namespace nbody
+namespace nbody { int read_sym_stamps(unsigned long long* out, int n_waves); }
+extern "C" int nbody_sym_read_stamps(unsigned long long* out, int n_waves) { return nbody::read_sym_stamps(out, n_waves); }
+extern "C" int nbody_sym_waves_per_simd = 4;
+extern "C" int nbody_sym_debug = 0;  // 4: diagnostic build with in-kernel cycle stamps  // tuning hook (NBODY_SYM_WAVES environment variable)
+namespace nbody {
+
+// ----------------------------------------------------------------------------------- host side
+SymPlan make_sym_plan(int n_upper) {
+    SymPlan p;
+    constexpr int IPT = 8;
+    p.ipt = IPT;
+    p.A = (n_upper + 64 * IPT - 1) / (64 * IPT);
+    p.sym_sets = (p.A + 1) / 2 - 1;             // ceil(A/2) - 1 sets are met symmetrically
+    const int L = IPT * p.sym_sets;              // chunk visits per set, all of equal cost
+    // waves per set: at most 1024 * waves_per_simd waves in all, so that every workgroup is resident
+    // at once, one (or two) per CU; the unused fraction of the last CU's slots is the only imbalance
+    p.wpb = (nbody_sym_waves_per_simd >= 6) ? 12 : 16;
+    const int slots = (p.wpb == 12) ? 6144 : 4096;
+    int K = slots / p.A;
+    if (K > 96) K = 96;
+    if (K > L) K = L;
+    if (K < 1) K = 1;
+    p.K = K;
+    p.n_planes = p.sym_sets + K + 1;             // travelling-side, resident-side (one per slice), own/opposite set
+    p.n_pad = size_t(p.A) * 64 * IPT;
+    p.bounds.resize(K + 1);
+    for (int part = 0; part <= K; ++part) p.bounds[part] = int((long long)L * part / K);
+    return p;
+}
+
+int read_sym_stamps(unsigned long long* out, int n_waves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbody_sym_stamps), sizeof(unsigned long long) * 3 * n_waves) == hipSuccess ? 0 : -1;
+}
+
+void launch_bf_forces_sym(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
+                          int n_upper, float g, float g_soft2) {
+    if (n_upper <= 0) return;
+    if (p.sym_sets > 0) {
+        const dim3 grid((p.A * p.K + p.wpb - 1) / p.wpb), block(p.wpb * 64);
+#define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.n_pad, g_soft2)
+        if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
+            if (p.wpb == 12) SYM_LAUNCH(12, 4); else SYM_LAUNCH(16, 4);
+        } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
+        } else if (nbody_sym_debug == 6) { SYM_LAUNCH(16, 6);
+        } else if (nbody_sym_debug == 7) { SYM_LAUNCH(16, 7);
+        } else {
+            if (p.wpb == 12) SYM_LAUNCH(12, 0); else SYM_LAUNCH(16, 0);
+        }
+#undef SYM_LAUNCH
+    }
+    float4* resident0 = planes + size_t(p.sym_sets) * p.n_pad;
+    if (p.sym_sets == 0)  // no symmetric pass: the resident-side planes are never written
+        (void)hipMemsetAsync(resident0, 0, size_t(p.K) * p.n_pad * sizeof(float4), s);
+    hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(), sh.own_count(), p.A,
+                       planes + size_t(p.n_planes - 1) * p.n_pad, g_soft2);
+    hipLaunchKernelGGL(k_bf_sym_reduce, dim3((n_upper + 255) / 256), dim3(256), 0, s, planes, p.n_planes, p.n_pad,
+                       sh.own_count(), g, sh.acc);
+}
+
+}  // namespace nbody

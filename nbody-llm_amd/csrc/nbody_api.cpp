@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 #include <vector>
 
 extern "C" int nbody_bf_fast_variant;
+extern "C" int nbody_sym_waves_per_simd;
 
 using nbody::BoundsF;
 using nbody::Shard;
@@ -59,6 +61,13 @@ struct NbodyHandle {
     std::vector<int32_t> own_order;
     unsigned long long* d_counters = nullptr;  // [2] accepted, visited
     unsigned long long* h_counters = nullptr;  // pinned
+
+    // symmetric all-pairs kernel (fast math, single shard, n >= kSymMinBodies)
+    nbody::SymPlan sym_plan;
+    int* d_sym_bounds = nullptr;
+    float4* d_planes = nullptr;
+    size_t planes_cap = 0;  // float4 entries
+    int sym_waves = 0;
 
     // diagnostics
     NbodyStats stats{};
@@ -200,11 +209,40 @@ int drain_events(NbodyHandle* h) {
     return NBODY_OK;
 }
 
+constexpr size_t kSymMinBodies = 8192;
+
+// (re)build the symmetric kernel's plan when the number of resident sets changes
+int ensure_sym_plan(NbodyHandle* h) {
+    const int A = int((h->n_local + 511) / 512);
+    if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == nbody_sym_waves_per_simd) return NBODY_OK;
+    h->sym_waves = nbody_sym_waves_per_simd;
+    h->sym_plan = nbody::make_sym_plan(int(h->n_local));
+    const nbody::SymPlan& p = h->sym_plan;
+    if (!h->d_sym_bounds) HIP_TRY(h, hipMalloc(&h->d_sym_bounds, 128 * sizeof(int)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sym_bounds, p.bounds.data(), p.bounds.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // p.bounds is pageable
+    const size_t need = size_t(p.n_planes) * p.n_pad;
+    if (need > h->planes_cap) {
+        if (h->d_planes) (void)hipFree(h->d_planes);
+        h->d_planes = nullptr; h->planes_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_planes, need * sizeof(float4)));
+        h->planes_cap = need;
+    }
+    return NBODY_OK;
+}
+
 int bf_forces(NbodyHandle* h) {
     const float eps2 = h->g_soft * h->g_soft;  // brute_force.rs:69
+    const bool sym = h->cfg.math_mode == NBODY_MATH_FAST && h->sh.n_seg == 1 && h->n_local >= kSymMinBodies &&
+                     nbody_bf_fast_variant == 0;
+    if (sym) {
+        int rc = ensure_sym_plan(h);
+        if (rc) return rc;
+    }
     {
         ForceTimer t(h);
         if (h->cfg.math_mode == NBODY_MATH_STRICT) nbody::launch_bf_forces_strict(h->stream, h->sh, int(h->n_local), h->g, eps2);
+        else if (sym) nbody::launch_bf_forces_sym(h->stream, h->sh, h->sym_plan, h->d_sym_bounds, h->d_planes, int(h->n_local), h->g, eps2);
         else nbody::launch_bf_forces_fast(h->stream, h->sh, int(h->n_local), h->g, eps2);
     }
     HIP_TRY(h, hipGetLastError());
@@ -322,7 +360,7 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_node_a, h->d_node_b, h->d_order, h->d_counters, h->d_energy};
+                   h->d_node_a, h->d_node_b, h->d_order, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -394,6 +432,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
+    if (const char* v = std::getenv("NBODY_SYM_WAVES")) nbody_sym_waves_per_simd = std::max(1, std::min(8, std::atoi(v)));
     *out = h;
     return NBODY_OK;
 }

@@ -208,6 +208,53 @@ def test_fast_accelerations_within_tolerance(gpu, orc, n, eps):
     assert np.max(num / den) < 1e-4
 
 
+@pytest.mark.parametrize("n,eps", [(8192, 0.0), (8193, 0.0), (8704, 1e-2), (9000, 0.0), (12345, 1e-2), (16384, 0.0),
+                                   (33000, 1e-2)])
+def test_fast_symmetric_kernel_sizes(gpu, orc, n, eps):
+    """n >= 8192 takes the symmetric kernel (kernels_bf_sym.hip): odd and even numbers of resident
+    sets (8193 -> 17 sets, 9000 -> 18), partial last set, zero softening (self and padding pairs)."""
+    nb = gpu
+    sd, st = settings(nb, g_soft=eps, g=1.25)
+    ics = nb.plummer(n, seed=n)
+    ics["mass"] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)  # unequal masses
+    ref = ics.copy().astype(orc.P32)
+    orc.bf_update_forces_rows(ref, sd, threads=8)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+    assert np.isfinite(got["acceleration"]).all()
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    num = np.linalg.norm(got["acceleration"].astype(np.float64) - ref["acceleration"], axis=1)
+    den = np.linalg.norm(ref["acceleration"].astype(np.float64), axis=1)
+    assert np.max(num / den) < 1e-4
+
+
+def test_fast_symmetric_kernel_is_deterministic_and_tracks_escapes(gpu, orc):
+    """Planes are summed in a fixed order (no atomics): two runs agree bit for bit; and the plan
+    follows the body count as bodies leave a tight box."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 3.0)
+    sd, st = settings(nb, dt=2e-2, g_soft=0.05)
+    ics = nb.plummer(10000, seed=5)
+    outs = []
+    for _ in range(2):
+        with nb.Simulation(ics, *box, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
+            sim.settings = st
+            sim.init()
+            for _ in range(3):
+                sim.steps(4)
+                n_now = len(sim)
+            outs.append(sim.get_points())
+    assert np.array_equal(outs[0], outs[1])
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(12):
+        ref = orc.bf_step_by(ref, sd, box[0], box[1], sd["dt"])
+    assert len(ref) < 9000 and len(outs[0]) == len(ref) == n_now
+    assert np.array_equal(outs[0]["mass"], ref["mass"])
+    assert rel_err(outs[0]["position"], ref["position"]) < 1e-5
+
+
 def test_fast_every_kernel_variant_agrees(gpu, orc):
     """All (bodies-per-lane, waves) instantiations of the fast kernel against the oracle, on a size
     that exercises partial tiles and the self-pair (diagonal) slices."""
