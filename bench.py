@@ -61,7 +61,7 @@ def cpu_baseline(orc, ics, settings, box, workload):
         t0 = time.perf_counter()
         orc.bf_update_forces(a, settings)
         dt = time.perf_counter() - t0
-        threads = orc.hardware_threads()
+        threads = min(16, orc.hardware_threads())   # a 1-GPU box's share of the host cores
         b = ics[: min(n, 32768)].astype(orc.P32)
         t0 = time.perf_counter()
         orc.bf_update_forces_rows(b, settings, threads=threads)
@@ -74,7 +74,7 @@ def cpu_baseline(orc, ics, settings, box, workload):
             "threaded_context": {"value": mb * (mb - 1) / dt_mt, "cores": threads,
                                  "sample": f"row-wise form, {mb} bodies, {dt_mt:.1f} s"},
         }
-    threads = orc.hardware_threads()
+    threads = min(16, orc.hardware_threads())       # a 1-GPU box's share of the host cores
     a = ics.astype(orc.P32)
     reps, acc = 3, 0
     t0 = time.perf_counter()
@@ -147,7 +147,7 @@ def main():
     if dist is not None:
         import torch
         t = torch.tensor([elapsed, float(stats.interactions), stats.force_kernel_ms, float(stats.force_launches),
-                          float(stats.node_visits)], dtype=torch.float64)
+                          float(stats.node_visits), float(stats.force_kernel_interactions)], dtype=torch.float64)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         elapsed = max(float(g[0]) for g in gathered)
@@ -155,8 +155,10 @@ def main():
         kernel_ms = max(float(g[2]) for g in gathered)   # the slowest rank's kernel time
         launches = float(gathered[0][3])
         visits = sum(float(g[4]) for g in gathered)
+        k_inter = float(gathered[0][5])                  # rank 0's dominant-kernel interactions
     else:
         interactions, kernel_ms, launches, visits = float(stats.interactions), stats.force_kernel_ms, float(stats.force_launches), float(stats.node_visits)
+        k_inter = float(stats.force_kernel_interactions)
 
     result = None
     if rank == 0:
@@ -166,8 +168,11 @@ def main():
         bodies_per_launch = n / world
         if args.workload == "bf":
             alg_bytes = BF_BYTES_PER_BODY * bodies_per_launch
-            kernel = "k_bf_fast" if args.math == "fast" else "k_bf_strict"
-            flops_per_launch = FLOP_PER_INTERACTION * bodies_per_launch * (n - 1)
+            kernel = ("k_bf_strict" if args.math == "strict" else
+                      "k_bf_sym" if (world == 1 and n >= 8192) else "k_bf_fast")
+            # interactions the timed (dominant) launches evaluated; k_bf_sym leaves ~2 % (own and
+            # opposite resident set) to the small companion kernel k_bf_sym_rest
+            flops_per_launch = FLOP_PER_INTERACTION * k_inter / max(1.0, launches)
         else:
             alg_bytes = BH_BYTES_PER_VISIT * (visits / world) / max(1.0, launches) + 32 * bodies_per_launch
             kernel = "k_bh_walk"
@@ -191,7 +196,8 @@ def main():
             # the all-pairs kernel is fp32-VALU bound, not HBM bound: this is
             # the fraction that says how good the kernel is
             roofline["alu"] = {"bound": "fp32-valu", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": tf / FP32_VALU_PEAK_TF, "flop_per_interaction": FLOP_PER_INTERACTION}
+                               "frac": tf / FP32_VALU_PEAK_TF, "flop_per_interaction": FLOP_PER_INTERACTION,
+                               "interactions_per_launch": k_inter / max(1.0, launches)}
         result = {
             "metric": "pairwise_interactions_per_sec", "value": value, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

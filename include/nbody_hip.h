@@ -74,7 +74,9 @@ typedef struct NbodyStats {
     uint64_t interactions;        /* bf: sum of n_own*(n_total-1) directed pairs; bh: accepted nodes */
     uint64_t node_visits;         /* bh: opening tests evaluated (0 for bf) */
     uint64_t tree_nodes;          /* bh: nodes in the last tree built */
-    uint64_t force_launches;      /* force-kernel launches timed since the last nbody_reset_stats */
+    uint64_t force_launches;      /* dominant-kernel launches timed since the last nbody_reset_stats */
+    uint64_t force_kernel_interactions; /* directed interactions those launches evaluated (bf: the
+                                     symmetric kernel leaves ~2 % to a small companion kernel) */
     double force_kernel_ms;       /* sum of their HIP-event durations (needs nbody_set_profiling(h,1)) */
     double tree_build_ms;         /* bh: host wall time in the octree build, summed */
     double tree_copy_ms;          /* bh: host wall time in D2H positions + H2D nodes, summed */

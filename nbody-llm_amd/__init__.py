@@ -68,7 +68,7 @@ class NbodyConfig(C.Structure):
 class NbodyStats(C.Structure):
     _fields_ = [
         ("steps", C.c_uint64), ("interactions", C.c_uint64), ("node_visits", C.c_uint64), ("tree_nodes", C.c_uint64),
-        ("force_launches", C.c_uint64), ("force_kernel_ms", C.c_double), ("tree_build_ms", C.c_double),
+        ("force_launches", C.c_uint64), ("force_kernel_interactions", C.c_uint64), ("force_kernel_ms", C.c_double), ("tree_build_ms", C.c_double),
         ("tree_copy_ms", C.c_double), ("exchange_ms", C.c_double),
     ]
 

@@ -56,13 +56,15 @@ struct SymPlan {
     std::vector<int> bounds;  // K+1 cut points of a set's chunk sequence
 };
 SymPlan make_sym_plan(int n_upper);
-void launch_bf_forces_sym(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
-                          int n_upper, float g, float g_soft2);
+uint64_t sym_main_pairs(const SymPlan& p, size_t n);  // unordered pairs of real bodies k_bf_sym evaluates
+void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
+                        int n_upper, float g_soft2);
+void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4* planes, int n_upper, float g,
+                        float g_soft2);
 
 // K5: BarnesHutSimulation::calc_force (barnes_hut.rs:185-203) over a linearised octree
 struct TreeDev {
-    const float4* node_a = nullptr;  // {com.x, com.y, com.z, mass}
-    const float4* node_b = nullptr;  // {width^2, skip (int bits), unused, unused}
+    const float4* nodes = nullptr;   // 2 per node: {com.x, com.y, com.z, mass}, {width^2, skip (int bits), width, leaf body}
     int n_nodes = 0;
     const int* order = nullptr;      // own bodies (index into the own segment) in tree order
     int n_order = 0;

@@ -26,6 +26,8 @@
 // fast math only (v_rsq_f32 + FMA; summation order differs from the reference): tolerance 1e-5.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace nbody {
 
 namespace {
@@ -285,22 +287,36 @@ int read_sym_stamps(unsigned long long* out, int n_waves) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbody_sym_stamps), sizeof(unsigned long long) * 3 * n_waves) == hipSuccess ? 0 : -1;
 }
 
-void launch_bf_forces_sym(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
-                          int n_upper, float g, float g_soft2) {
-    if (n_upper <= 0) return;
-    if (p.sym_sets > 0) {
-        const dim3 grid((p.A * p.K + p.wpb - 1) / p.wpb), block(p.wpb * 64);
+uint64_t sym_main_pairs(const SymPlan& p, size_t n) {
+    const size_t set = size_t(64) * p.ipt;
+    auto size_of = [&](int a) { size_t lo = size_t(a) * set; return lo >= n ? size_t(0) : std::min(set, n - lo); };
+    uint64_t pairs = 0;
+    for (int a = 0; a < p.A; ++a)
+        for (int d = 1; d <= p.sym_sets; ++d) pairs += uint64_t(size_of(a)) * uint64_t(size_of((a + d) % p.A));
+    return pairs;
+}
+
+// the rotation kernel alone (the dominant launch: bench.py times it with HIP events)
+void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
+                        int n_upper, float g_soft2) {
+    if (n_upper <= 0 || p.sym_sets <= 0) return;
+    const dim3 grid((p.A * p.K + p.wpb - 1) / p.wpb), block(p.wpb * 64);
 #define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.n_pad, g_soft2)
-        if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
-            if (p.wpb == 12) SYM_LAUNCH(12, 4); else SYM_LAUNCH(16, 4);
-        } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
-        } else if (nbody_sym_debug == 6) { SYM_LAUNCH(16, 6);
-        } else if (nbody_sym_debug == 7) { SYM_LAUNCH(16, 7);
-        } else {
-            if (p.wpb == 12) SYM_LAUNCH(12, 0); else SYM_LAUNCH(16, 0);
-        }
-#undef SYM_LAUNCH
+    if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
+        if (p.wpb == 12) SYM_LAUNCH(12, 4); else SYM_LAUNCH(16, 4);
+    } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
+    } else if (nbody_sym_debug == 6) { SYM_LAUNCH(16, 6);
+    } else if (nbody_sym_debug == 7) { SYM_LAUNCH(16, 7);
+    } else {
+        if (p.wpb == 12) SYM_LAUNCH(12, 0); else SYM_LAUNCH(16, 0);
     }
+#undef SYM_LAUNCH
+}
+
+// own/opposite-set pairs + the fixed-order sum of the planes into acc
+void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4* planes, int n_upper, float g,
+                        float g_soft2) {
+    if (n_upper <= 0) return;
     float4* resident0 = planes + size_t(p.sym_sets) * p.n_pad;
     if (p.sym_sets == 0)  // no symmetric pass: the resident-side planes are never written
         (void)hipMemsetAsync(resident0, 0, size_t(p.K) * p.n_pad * sizeof(float4), s);

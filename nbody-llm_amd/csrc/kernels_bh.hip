@@ -22,9 +22,11 @@ namespace nbody {
 
 constexpr int kWalkBlock = 256;
 
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+struct alignas(32) NodeDev { float4 a; float4 b; };  // {com, mass}, {width^2, skip bits, width, leaf body}
+
 template <bool FAST>
-__global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const float4* __restrict__ node_a,
-                                                        const float4* __restrict__ node_b, int n_nodes,
+__global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restrict__ nodes, int n_nodes,
                                                         const int* __restrict__ order, int n_order,
                                                         const float4* __restrict__ own_pos, float4* __restrict__ acc,
                                                         float g, float eps2, float theta2,
@@ -37,8 +39,8 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const float4* __restrict
         float ax = 0.f, ay = 0.f, az = 0.f;
         int i = 0;
         while (i < n_nodes) {
-            const float4 A = node_a[i];
-            const float4 B = node_b[i];
+            const float4 A = nodes[i].a;
+            const float4 B = nodes[i].b;
             const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
             const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
             ++n_vis;
@@ -72,16 +74,83 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const float4* __restrict
     }
 }
 
+// Wave-cooperative form of the same walk.  The 64 lanes of a wave hold 64 neighbouring bodies
+// (tree order) and step through the UNION of their node sequences together: the node index is
+// wave-uniform, so the 32-byte node record arrives by scalar load in SGPRs (no divergent gather),
+// and each lane only remembers `resume`, the index at which it becomes interested again after
+// accepting a node (= that node's skip link).  A lane evaluates node i iff i >= resume, i.e. iff
+// its own sequential walk would visit it; the wave steps to i + 1 while any lane still wants the
+// children, else to the skip link.  Per lane the accepted nodes, their order and the counters are
+// exactly those of k_bh_walk (and of the reference recursion); only the memory access pattern
+// changes.  With one wave per SIMD (N = 65 536 is only 1 024 waves) the dependent scalar-load chain is
+// exposed, so this form is slower than k_bh_walk today (1.26 vs 0.83 ms); it needs the node range
+// split over several waves per body group to pay off (Barnes-Hut, next steps).
+template <bool FAST>
+__global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __restrict__ nodes, int n_nodes,
+                                                             const int* __restrict__ order, int n_order,
+                                                             const float4* __restrict__ own_pos,
+                                                             float4* __restrict__ acc, float g, float eps2,
+                                                             float theta2, unsigned long long* __restrict__ counters) {
+    const int t = blockIdx.x * kWalkBlock + threadIdx.x;
+    const bool live = t < n_order;
+    const int b = live ? order[t] : 0;
+    const float4 p = live ? own_pos[b] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    unsigned int n_acc = 0, n_vis = 0;
+    int resume = live ? 0 : 0x7fffffff;  // dead lanes never look at a node
+    int i = 0;                           // wave-uniform node index
+    while (i < n_nodes) {
+        // uniform address: ONE 32-byte scalar load (left to itself the compiler fetches the mass in a
+        // third, dependent s_load under the accept branch)
+        f32x8 rec;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(nodes + i) : "memory");
+        const float4 A = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        const float4 B = make_float4(rec[4], rec[5], rec[6], rec[7]);
+        const bool active = i >= resume;
+        const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
+        const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
+        const bool accept = active && (B.x < theta2 * r2);                  // :192
+        n_vis += active ? 1u : 0u;
+        if (accept) {
+            float k;
+            if (FAST) {
+                const float rinv = __builtin_amdgcn_rsqf(r2 + eps2);
+                k = (g * A.w) * ((rinv * rinv) * rinv);
+            } else {
+                const float r_dist = __builtin_sqrtf(r2 + eps2);            // :193
+                const float r_cubed = r_dist * r_dist * r_dist;             // :194
+                k = ((g * A.w) / r_cubed);                                  // :195
+            }
+            ax += rx * k; ay += ry * k; az += rz * k;
+            ++n_acc;
+            resume = __float_as_int(B.y);
+        }
+        const bool wants_children = active && !accept;
+        i = __builtin_amdgcn_readfirstlane(__ballot(wants_children) != 0ull ? i + 1 : __float_as_int(B.y));
+    }
+    if (live) acc[b] = make_float4(ax, ay, az, 0.f);                        // overwrite, :260
+    for (int off = 32; off > 0; off >>= 1) {
+        n_acc += __shfl_down(n_acc, off);
+        n_vis += __shfl_down(n_vis, off);
+    }
+    if ((threadIdx.x & 63) == 0 && counters) {
+        atomicAdd(&counters[0], (unsigned long long)n_acc);
+        atomicAdd(&counters[1], (unsigned long long)n_vis);
+    }
+}
+
+}  // namespace nbody
+extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative
+namespace nbody {
+
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters) {
     if (t.n_order <= 0) return;
     int blocks = (t.n_order + kWalkBlock - 1) / kWalkBlock;
-    if (fast_math)
-        hipLaunchKernelGGL(k_bh_walk<true>, dim3(blocks), dim3(kWalkBlock), 0, s, t.node_a, t.node_b, t.n_nodes,
-                           t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters);
-    else
-        hipLaunchKernelGGL(k_bh_walk<false>, dim3(blocks), dim3(kWalkBlock), 0, s, t.node_a, t.node_b, t.n_nodes,
-                           t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters);
+#define WALK(K, F) hipLaunchKernelGGL(K<F>, dim3(blocks), dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters)
+    if (nbody_bh_walk_variant == 1) { if (fast_math) WALK(k_bh_walk_wave, true); else WALK(k_bh_walk_wave, false); }
+    else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
+#undef WALK
 }
 
 }  // namespace nbody

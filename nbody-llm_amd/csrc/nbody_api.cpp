@@ -52,8 +52,8 @@ struct NbodyHandle {
     // Barnes-Hut
     std::unique_ptr<nbody::WorkerPool> pool;
     nbody::HostTree tree;
-    float4* d_node_a = nullptr;
-    float4* d_node_b = nullptr;
+    nbody::BuildScratch tree_scratch;
+    float4* d_nodes = nullptr;  // 2 float4 per node: {com, mass}, {width^2, skip, width, leaf body}
     int* d_order = nullptr;
     size_t d_node_cap = 0, d_order_cap = 0;
     float* h_pos = nullptr;    // pinned: all segments' positions
@@ -68,6 +68,8 @@ struct NbodyHandle {
     float4* d_planes = nullptr;
     size_t planes_cap = 0;  // float4 entries
     int sym_waves = 0;
+    uint64_t sym_pairs = 0;   // unordered pairs the rotation kernel covers at the current n_local
+    size_t sym_pairs_n = 0;
 
     // diagnostics
     NbodyStats stats{};
@@ -239,26 +241,33 @@ int bf_forces(NbodyHandle* h) {
         int rc = ensure_sym_plan(h);
         if (rc) return rc;
     }
+    if (sym && h->sym_pairs_n != h->n_local) {
+        h->sym_pairs = nbody::sym_main_pairs(h->sym_plan, h->n_local);
+        h->sym_pairs_n = h->n_local;
+    }
     {
-        ForceTimer t(h);
+        ForceTimer t(h);  // HIP events around the dominant launch only
         if (h->cfg.math_mode == NBODY_MATH_STRICT) nbody::launch_bf_forces_strict(h->stream, h->sh, int(h->n_local), h->g, eps2);
-        else if (sym) nbody::launch_bf_forces_sym(h->stream, h->sh, h->sym_plan, h->d_sym_bounds, h->d_planes, int(h->n_local), h->g, eps2);
+        else if (sym) nbody::launch_bf_sym_main(h->stream, h->sh, h->sym_plan, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
         else nbody::launch_bf_forces_fast(h->stream, h->sh, int(h->n_local), h->g, eps2);
     }
+    if (sym) nbody::launch_bf_sym_tail(h->stream, h->sh, h->sym_plan, h->d_planes, int(h->n_local), h->g, eps2);
     HIP_TRY(h, hipGetLastError());
     size_t tot = total_upper(h);
-    if (tot > 0) h->stats.interactions += uint64_t(h->n_local) * uint64_t(tot - 1);
+    if (tot > 0) {
+        const uint64_t all = uint64_t(h->n_local) * uint64_t(tot - 1);
+        h->stats.interactions += all;
+        if (h->profiling) h->stats.force_kernel_interactions += sym ? 2 * h->sym_pairs : all;
+    }
     return NBODY_OK;
 }
 
 int ensure_tree_dev(NbodyHandle* h, size_t nodes, size_t order) {
     if (nodes > h->d_node_cap) {
-        if (h->d_node_a) (void)hipFree(h->d_node_a);
-        if (h->d_node_b) (void)hipFree(h->d_node_b);
-        h->d_node_a = h->d_node_b = nullptr; h->d_node_cap = 0;
+        if (h->d_nodes) (void)hipFree(h->d_nodes);
+        h->d_nodes = nullptr; h->d_node_cap = 0;
         size_t cap = nodes + nodes / 4 + 1024;
-        HIP_TRY(h, hipMalloc(&h->d_node_a, cap * sizeof(float4)));
-        HIP_TRY(h, hipMalloc(&h->d_node_b, cap * sizeof(float4)));
+        HIP_TRY(h, hipMalloc(&h->d_nodes, cap * 2 * sizeof(float4)));
         h->d_node_cap = cap;
     }
     if (order > h->d_order_cap) {
@@ -291,7 +300,7 @@ int bh_forces(NbodyHandle* h) {
     double copy_ms = ms_since(t0);
 
     auto t1 = clk::now();
-    nbody::build_octree(h->h_pos, sh.n_seg, sh.seg_cap, h->h_counts, h->center, h->width, *h->pool, h->tree);
+    nbody::build_octree(h->h_pos, sh.n_seg, sh.seg_cap, h->h_counts, h->center, h->width, *h->pool, h->tree_scratch, h->tree);
     if (h->tree.too_deep) return fail(h, NBODY_ERR_TREE_DEPTH, "octree deeper than NBODY_MAX_TREE_DEPTH (coincident bodies?)");
     // bodies of the own segment in tree order (ids are s*seg_cap + j)
     const int32_t* order = h->tree.order;
@@ -312,14 +321,13 @@ int bh_forces(NbodyHandle* h) {
     auto t2 = clk::now();
     int rc = ensure_tree_dev(h, h->tree.n_nodes, n_order);
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_node_a, h->tree.a, h->tree.n_nodes * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_node_b, h->tree.b, h->tree.n_nodes * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_nodes, h->tree.nodes, h->tree.n_nodes * sizeof(nbody::NodeRec), hipMemcpyHostToDevice, h->stream));
     if (n_order) HIP_TRY(h, hipMemcpyAsync(h->d_order, order, n_order * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (sh.n_seg > 1) HIP_TRY(h, hipStreamSynchronize(h->stream));  // own_order is pageable and reused
     h->stats.tree_copy_ms += copy_ms + ms_since(t2);
 
     nbody::TreeDev td;
-    td.node_a = h->d_node_a; td.node_b = h->d_node_b; td.n_nodes = int(h->tree.n_nodes);
+    td.nodes = h->d_nodes; td.n_nodes = int(h->tree.n_nodes);
     td.order = h->d_order; td.n_order = int(n_order);
     {
         ForceTimer t(h);
@@ -360,7 +368,7 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_node_a, h->d_node_b, h->d_order, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes};
+                   h->d_nodes, h->d_order, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -419,7 +427,9 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     CREATE_TRY(hipHostMalloc(&h->h_counts, sizeof(int) * sh.n_seg, hipHostMallocDefault));
     h->seg_count_host.assign(sh.n_seg, 0);
     if (cfg->method == NBODY_BARNES_HUT) {
-        int threads = cfg->host_threads > 0 ? cfg->host_threads : int(std::thread::hardware_concurrency());
+        // default: the cores this process may run on, at most 16 (a GPU's share of the host; more
+        // threads than top-level subtrees only add wake-up latency)
+        int threads = cfg->host_threads > 0 ? cfg->host_threads : std::min(16, std::max(1, int(std::thread::hardware_concurrency()) - 2));
         if (threads < 1) threads = 1;
         h->pool.reset(new nbody::WorkerPool(threads));
         h->tree.alloc = pinned_alloc;
@@ -691,6 +701,7 @@ int nbody_stats(NbodyHandle* h, NbodyStats* out) {
         HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->stats.interactions = h->h_counters[0];
+        h->stats.force_kernel_interactions = h->h_counters[0];  // the walk kernel evaluates all of them
         h->stats.node_visits = h->h_counters[1];
     }
     *out = h->stats;
@@ -749,9 +760,10 @@ int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* sk
     if (!com_mass && !width && !skip) return NBODY_OK;
     if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "tree export buffer too small");
     for (size_t i = 0; i < n; ++i) {
-        if (com_mass) { com_mass[4 * i] = h->tree.a[i].x; com_mass[4 * i + 1] = h->tree.a[i].y; com_mass[4 * i + 2] = h->tree.a[i].z; com_mass[4 * i + 3] = h->tree.a[i].m; }
-        if (width) width[i] = h->tree.b[i].w;
-        if (skip) skip[i] = h->tree.b[i].skip;
+        const nbody::NodeRec& r = h->tree.nodes[i];
+        if (com_mass) { com_mass[4 * i] = r.a.x; com_mass[4 * i + 1] = r.a.y; com_mass[4 * i + 2] = r.a.z; com_mass[4 * i + 3] = r.a.m; }
+        if (width) width[i] = r.b.w;
+        if (skip) skip[i] = r.b.skip;
     }
     return NBODY_OK;
 }
@@ -793,19 +805,26 @@ int nbody_host_build_tree(const float* pos4, size_t n, const float center[3], fl
                           size_t cap, size_t* n_nodes) {
     if ((!pos4 && n) || !center || !n_nodes) return NBODY_ERR_INVALID;
     if (n > (1ull << 30)) return NBODY_ERR_INVALID;
-    nbody::WorkerPool pool(threads > 0 ? threads : 1);
-    nbody::HostTree tree;
+    // pool, scratch and output arrays persist per calling thread (repeat calls time the build itself)
+    static thread_local std::unique_ptr<nbody::WorkerPool> tl_pool;
+    static thread_local int tl_threads = 0;
+    static thread_local nbody::BuildScratch scratch;
+    static thread_local nbody::HostTree tree;
+    const int want = threads > 0 ? threads : 1;
+    if (!tl_pool || tl_threads != want) { tl_pool.reset(new nbody::WorkerPool(want)); tl_threads = want; }
+    nbody::WorkerPool& pool = *tl_pool;
     int cnt = int(n);
-    nbody::build_octree(pos4, 1, int(n), &cnt, center, width, pool, tree);
+    nbody::build_octree(pos4, 1, int(n), &cnt, center, width, pool, scratch, tree);
     if (tree.too_deep) return NBODY_ERR_TREE_DEPTH;
     *n_nodes = tree.n_nodes;
     if (!com_mass) return NBODY_OK;
     if (tree.n_nodes > cap) return NBODY_ERR_CAPACITY;
     for (size_t i = 0; i < tree.n_nodes; ++i) {
-        com_mass[4 * i] = tree.a[i].x; com_mass[4 * i + 1] = tree.a[i].y; com_mass[4 * i + 2] = tree.a[i].z; com_mass[4 * i + 3] = tree.a[i].m;
-        if (node_width) node_width[i] = tree.b[i].w;
-        if (skip) skip[i] = tree.b[i].skip;
-        if (leaf_body) leaf_body[i] = tree.b[i].body;
+        const nbody::NodeRec& r = tree.nodes[i];
+        com_mass[4 * i] = r.a.x; com_mass[4 * i + 1] = r.a.y; com_mass[4 * i + 2] = r.a.z; com_mass[4 * i + 3] = r.a.m;
+        if (node_width) node_width[i] = r.b.w;
+        if (skip) skip[i] = r.b.skip;
+        if (leaf_body) leaf_body[i] = r.b.body;
     }
     if (order) std::memcpy(order, tree.order, tree.n_order * sizeof(int32_t));
     return NBODY_OK;

@@ -23,9 +23,12 @@
 #include "octree_host.h"
 #include "../../include/nbody_hip.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
+#include <array>
 
 namespace nbody {
 
@@ -39,33 +42,39 @@ WorkerPool::~WorkerPool() {
     {
         std::lock_guard<std::mutex> lk(m_);
         stop_ = true;
+        stop_a_.store(true);
     }
     cv_.notify_all();
     for (auto& t : workers_) t.join();
 }
 
+// Workers spin on the epoch counter for a while before they sleep on the condition variable: a
+// Barnes-Hut step calls run() five times within ~2 ms, and a futex wake-up per call per worker
+// (tens of microseconds each) would cost as much as the partition work itself.
 void WorkerPool::loop() {
     uint64_t seen = 0;
     for (;;) {
-        const std::function<void(int)>* fn;
-        int n;
-        {
-            std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-            if (stop_) return;
-            seen = epoch_;
-            fn = fn_;
-            n = n_tasks_;
+        bool got = false;
+        for (int spin = 0; spin < 4000; ++spin) {  // ~0.1 ms
+            if (epoch_a_.load(std::memory_order_acquire) != seen || stop_a_.load(std::memory_order_relaxed)) { got = true; break; }
+            __builtin_ia32_pause();
         }
+        if (!got) {
+            std::unique_lock<std::mutex> lk(m_);
+            sleepers_++;
+            cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+            sleepers_--;
+        }
+        if (stop_a_.load(std::memory_order_relaxed)) return;
+        seen = epoch_a_.load(std::memory_order_acquire);
+        const std::function<void(int)>* fn = fn_;
+        const int n = n_tasks_;
         for (;;) {
             int t = next_.fetch_add(1, std::memory_order_relaxed);
             if (t >= n) break;
             (*fn)(t);
         }
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            if (--active_ == 0) done_cv_.notify_all();
-        }
+        active_a_.fetch_sub(1, std::memory_order_acq_rel);
     }
 }
 
@@ -75,43 +84,42 @@ void WorkerPool::run(int n_tasks, const std::function<void(int)>& fn) {
         for (int t = 0; t < n_tasks; ++t) fn(t);
         return;
     }
+    bool wake;
     {
         std::lock_guard<std::mutex> lk(m_);
         fn_ = &fn;
         n_tasks_ = n_tasks;
         next_.store(0, std::memory_order_relaxed);
-        active_ = int(workers_.size());
+        active_a_.store(int(workers_.size()), std::memory_order_relaxed);
         ++epoch_;
+        epoch_a_.store(epoch_, std::memory_order_release);
+        wake = sleepers_ > 0;
     }
-    cv_.notify_all();
+    if (wake) cv_.notify_all();
     for (;;) {  // the caller works too
         int t = next_.fetch_add(1, std::memory_order_relaxed);
         if (t >= n_tasks) break;
         fn(t);
     }
-    std::unique_lock<std::mutex> lk(m_);
-    done_cv_.wait(lk, [&] { return active_ == 0; });
+    while (active_a_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();  // every worker has left fn
 }
 
 // ------------------------------------------------------------------------------ output arrays
 void HostTree::clear() {
     auto rel = release ? release : +[](void* p) { std::free(p); };
-    if (a) rel(a);
-    if (b) rel(b);
+    if (nodes) rel(nodes);
     if (order) rel(order);
-    a = nullptr; b = nullptr; order = nullptr;
+    nodes = nullptr; order = nullptr;
     cap_nodes = cap_order = n_nodes = n_order = 0;
 }
 
-void HostTree::reserve(size_t nodes, size_t order_n) {
+void HostTree::reserve(size_t n_nodes_wanted, size_t order_n) {
     auto al = alloc ? alloc : +[](size_t n) { return std::malloc(n); };
     auto rel = release ? release : +[](void* p) { std::free(p); };
-    if (nodes > cap_nodes) {
-        size_t cap = nodes + nodes / 4 + 64;
-        if (a) rel(a);
-        if (b) rel(b);
-        a = static_cast<NodeA*>(al(cap * sizeof(NodeA)));
-        b = static_cast<NodeB*>(al(cap * sizeof(NodeB)));
+    if (n_nodes_wanted > cap_nodes) {
+        size_t cap = n_nodes_wanted + n_nodes_wanted / 4 + 64;
+        if (nodes) rel(nodes);
+        nodes = static_cast<NodeRec*>(al(cap * sizeof(NodeRec)));
         cap_nodes = cap;
     }
     if (order_n > cap_order) {
@@ -140,8 +148,7 @@ struct Box {
 };
 
 struct Emit {
-    std::vector<NodeA> a;
-    std::vector<NodeB> b;
+    std::vector<NodeRec> nodes;
     std::vector<int32_t> order;
     bool too_deep = false;
 };
@@ -175,13 +182,12 @@ inline void scatter(const Item* src, Item* dst, const uint8_t* code, int n, cons
 }
 
 void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int depth, Emit& e) {
-    const int me = int(e.a.size());
-    e.a.push_back(NodeA{0.f, 0.f, 0.f, 0.f});
-    e.b.push_back(NodeB{box.w * box.w, me + 1, box.w, -1});
+    const int me = int(e.nodes.size());
+    e.nodes.push_back(NodeRec{NodeA{0.f, 0.f, 0.f, 0.f}, NodeB{box.w * box.w, me + 1, box.w, -1}});
     if (n == 0) return;
     if (n == 1) {
-        e.a[me] = NodeA{src[0].x, src[0].y, src[0].z, src[0].m};
-        e.b[me].body = src[0].id;
+        e.nodes[me].a = NodeA{src[0].x, src[0].y, src[0].z, src[0].m};
+        e.nodes[me].b.body = src[0].id;
         e.order.push_back(src[0].id);
         return;
     }
@@ -192,13 +198,13 @@ void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
     scatter(src, tmp, code, n, cnt, start);
     for (int o = 0; o < 8; ++o)
         if (cnt[o]) build_rec(tmp + start[o], src + start[o], code + start[o], cnt[o], box.child(o), depth + 1, e);
-    e.a[me] = node;
-    e.b[me].skip = int(e.a.size());
+    e.nodes[me].a = node;
+    e.nodes[me].b.skip = int(e.nodes.size());
 }
 
 constexpr int kTaskDepth = 2;
 
-struct Task { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; Emit out; };
+struct Task { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; Emit* out; };
 
 struct TopEntry {
     int task = -1;   // >= 0: the subtree built by that task; else a node of the top levels
@@ -222,7 +228,7 @@ void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
     if (depth >= kTaskDepth) {
         top[me].task = int(tasks.size());
         top[me].end = me + 1;
-        tasks.push_back(Task{src, tmp, code, n, box, depth, Emit{}});
+        tasks.push_back(Task{src, tmp, code, n, box, depth, nullptr});
         return;
     }
     int cnt[8], start[8];
@@ -237,42 +243,143 @@ void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
 
 }  // namespace
 
+struct BuildScratch::Impl {
+    std::vector<Item> buf_a, buf_b;
+    std::vector<uint8_t> code;
+    std::vector<Emit> emits;  // one per subtree task; capacities survive from step to step
+};
+BuildScratch::BuildScratch() : impl(new Impl) {}
+BuildScratch::~BuildScratch() { delete impl; }
+
 void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, const float center[3], float width,
-                  WorkerPool& pool, HostTree& out) {
+                  WorkerPool& pool, BuildScratch& scratch, HostTree& out) {
     size_t n = 0;
-    for (int s = 0; s < n_seg; ++s) n += size_t(count[s]);
-    static thread_local std::vector<Item> buf_a, buf_b;
-    static thread_local std::vector<uint8_t> code;
-    buf_a.resize(n); buf_b.resize(n); code.resize(n);
-    size_t k = 0;
-    for (int s = 0; s < n_seg; ++s)
-        for (int j = 0; j < count[s]; ++j, ++k) {
-            const float* p = pos4 + 4 * (size_t(s) * seg_cap + j);
-            buf_a[k] = Item{p[0], p[1], p[2], p[3], int32_t(s * seg_cap + j)};
-        }
+    std::vector<size_t> seg_first(n_seg + 1, 0);
+    for (int s = 0; s < n_seg; ++s) { seg_first[s] = n; n += size_t(count[s]); }
+    seg_first[n_seg] = n;
+    // all working memory is kept between calls: in a VM a fresh 10 MB costs more in page faults
+    // than the build itself
+    std::vector<Item>& buf_a = scratch.impl->buf_a;
+    std::vector<Item>& buf_b = scratch.impl->buf_b;
+    std::vector<uint8_t>& code = scratch.impl->code;
+    std::vector<Emit>& emits = scratch.impl->emits;
+    if (buf_a.size() < n) { buf_a.resize(n); buf_b.resize(n); code.resize(n); }
+    Item* A = buf_a.data();
+    Item* B = buf_b.data();
+    uint8_t* C = code.data();
+
     Box root;
     root.c[0] = center[0]; root.c[1] = center[1]; root.c[2] = center[2];
     root.hw = width * 0.5f;  // Bounds::new, shared.rs:236-243
     root.w = width;
 
+    const int T = pool.size();
+    static const bool timing = std::getenv("NBODY_TREE_TIMING") != nullptr;
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  octree %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+        t_start = now;
+    };
+    auto fill = [&](size_t k0, size_t k1) {  // bodies enter in id order = the reference's vector order
+        int s = 0;
+        while (seg_first[s + 1] <= k0 && s + 1 < n_seg) ++s;
+        for (size_t k = k0; k < k1; ++k) {
+            while (k >= seg_first[s + 1]) ++s;
+            const size_t j = k - seg_first[s];
+            const float* p = pos4 + 4 * (size_t(s) * seg_cap + j);
+            A[k] = Item{p[0], p[1], p[2], p[3], int32_t(size_t(s) * seg_cap + j)};
+        }
+    };
+
     std::vector<TopEntry> top;
     std::vector<Task> tasks;
-    build_top(buf_a.data(), buf_b.data(), code.data(), int(n), root, 0, top, tasks);
+    if (n < 8192 || T == 1) {
+        fill(0, n);
+        build_top(A, B, C, int(n), root, 0, top, tasks);
+    } else {
+        // ---- level 0 in parallel: chunked classify + stable scatter; the root's sums are one
+        // sequential fold (their order is the reference's) running beside the chunk tasks
+        const int NC = T;
+        const size_t chunk = (n + NC - 1) / NC;
+        std::vector<std::array<int, 8>> cnt(NC);
+        NodeA root_node{0.f, 0.f, 0.f, 0.f};
+        pool.run(NC, [&](int t) {
+            const size_t k0 = std::min(n, size_t(t) * chunk), k1 = std::min(n, k0 + chunk);
+            fill(k0, k1);
+            std::array<int, 8> c{};
+            for (size_t k = k0; k < k1; ++k) {
+                const Item& it = A[k];
+                int o = (it.x > root.c[0] ? 1 : 0) | (it.y > root.c[1] ? 2 : 0) | (it.z > root.c[2] ? 4 : 0);
+                C[k] = uint8_t(o);
+                c[o]++;
+            }
+            cnt[t] = c;
+        });
+        int start[8], tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < NC; ++t) for (int o = 0; o < 8; ++o) tot[o] += cnt[t][o];
+        { int run = 0; for (int o = 0; o < 8; ++o) { start[o] = run; run += tot[o]; } }
+        std::vector<std::array<int, 8>> off(NC);
+        { int run[8]; for (int o = 0; o < 8; ++o) run[o] = start[o];
+          for (int t = 0; t < NC; ++t) for (int o = 0; o < 8; ++o) { off[t][o] = run[o]; run[o] += cnt[t][o]; } }
+        pool.run(NC + 1, [&](int t) {
+            if (t == NC) {  // mass = sum m, com = sum(pos*m)/mass, folded left to right over all bodies
+                float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+                for (size_t k = 0; k < n; ++k) {
+                    const Item& it = A[k];
+                    mass += it.m; sx += it.x * it.m; sy += it.y * it.m; sz += it.z * it.m;
+                }
+                root_node = NodeA{sx / mass, sy / mass, sz / mass, mass};
+                return;
+            }
+            const size_t k0 = std::min(n, size_t(t) * chunk), k1 = std::min(n, k0 + chunk);
+            int o8[8];
+            for (int o = 0; o < 8; ++o) o8[o] = off[t][o];
+            for (size_t k = k0; k < k1; ++k) B[o8[C[k]]++] = A[k];
+        });
+        // ---- level 1: one task per non-empty orthant; each registers its depth-2 subtrees
+        std::vector<std::vector<TopEntry>> ctop(8);
+        std::vector<std::vector<Task>> ctasks(8);
+        pool.run(8, [&](int o) {
+            if (tot[o]) build_top(B + start[o], A + start[o], C + start[o], tot[o], root.child(o), 1, ctop[o], ctasks[o]);
+        });
+        top.emplace_back();
+        top[0].a = root_node;
+        top[0].b = NodeB{root.w * root.w, 0, root.w, -1};
+        for (int o = 0; o < 8; ++o) {
+            const int ebase = int(top.size()), tbase = int(tasks.size());
+            for (TopEntry e : ctop[o]) {
+                if (e.task >= 0) e.task += tbase;
+                e.end += ebase;
+                top.push_back(e);
+            }
+            for (Task& t : ctasks[o]) tasks.push_back(t);
+        }
+        top[0].end = int(top.size());
+    }
 
-    pool.run(int(tasks.size()), [&](int t) {
-        Task& tk = tasks[t];
-        tk.out.a.reserve(size_t(tk.n) * 2);
-        tk.out.b.reserve(size_t(tk.n) * 2);
-        tk.out.order.reserve(tk.n);
-        build_rec(tk.src, tk.tmp, tk.code, tk.n, tk.box, tk.depth, tk.out);
+    lap("top");
+    // larger subtrees first: the dynamic hand-out then ends on small ones
+    std::vector<int> by_size(tasks.size());
+    for (size_t i = 0; i < tasks.size(); ++i) by_size[i] = int(i);
+    std::sort(by_size.begin(), by_size.end(), [&](int x, int y) { return tasks[x].n > tasks[y].n; });
+    if (emits.size() < tasks.size()) emits.resize(tasks.size());
+    for (size_t i = 0; i < tasks.size(); ++i) tasks[i].out = &emits[i];
+    pool.run(int(tasks.size()), [&](int i) {
+        Task& tk = tasks[by_size[i]];
+        Emit& e = *tk.out;
+        e.nodes.clear(); e.order.clear(); e.too_deep = false;
+        build_rec(tk.src, tk.tmp, tk.code, tk.n, tk.box, tk.depth, e);
     });
 
+    lap("subtrees");
     // splice: final index of every top entry = prefix sum of entry sizes
     std::vector<int> first(top.size() + 1, 0);
     std::vector<int> ofirst(top.size() + 1, 0);
     for (size_t e = 0; e < top.size(); ++e) {
-        int sz = top[e].task >= 0 ? int(tasks[top[e].task].out.a.size()) : 1;
-        int osz = top[e].task >= 0 ? int(tasks[top[e].task].out.order.size()) : (top[e].b.body >= 0 ? 1 : 0);
+        int sz = top[e].task >= 0 ? int(tasks[top[e].task].out->nodes.size()) : 1;
+        int osz = top[e].task >= 0 ? int(tasks[top[e].task].out->order.size()) : (top[e].b.body >= 0 ? 1 : 0);
         first[e + 1] = first[e] + sz;
         ofirst[e + 1] = ofirst[e] + osz;
     }
@@ -283,26 +390,25 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
     out.too_deep = false;
     for (size_t e = 0; e < top.size(); ++e) {
         if (top[e].task < 0) {
-            out.a[first[e]] = top[e].a;
             NodeB b = top[e].b;
             b.skip = first[top[e].end];
-            out.b[first[e]] = b;
+            out.nodes[first[e]] = NodeRec{top[e].a, b};
             if (b.body >= 0) out.order[ofirst[e]] = b.body;
         }
     }
     pool.run(int(top.size()), [&](int e) {
         if (top[e].task < 0) return;
-        const Emit& em = tasks[top[e].task].out;
+        const Emit& em = *tasks[top[e].task].out;
         const int base = first[e];
-        std::memcpy(&out.a[base], em.a.data(), em.a.size() * sizeof(NodeA));
-        for (size_t i = 0; i < em.b.size(); ++i) {
-            NodeB b = em.b[i];
-            b.skip += base;
-            out.b[base + i] = b;
+        for (size_t i = 0; i < em.nodes.size(); ++i) {
+            NodeRec r = em.nodes[i];
+            r.b.skip += base;
+            out.nodes[base + i] = r;
         }
         if (!em.order.empty()) std::memcpy(&out.order[ofirst[e]], em.order.data(), em.order.size() * sizeof(int32_t));
     });
-    for (auto& tk : tasks) out.too_deep = out.too_deep || tk.out.too_deep;
+    for (auto& tk : tasks) out.too_deep = out.too_deep || tk.out->too_deep;
+    lap("splice");
 }
 
 }  // namespace nbody

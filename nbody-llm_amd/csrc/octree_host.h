@@ -26,30 +26,33 @@ private:
     void loop();
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(int)>* fn_ = nullptr;
     std::atomic<int> next_{0};
+    std::atomic<int> active_a_{0};
+    std::atomic<uint64_t> epoch_a_{0};
+    std::atomic<bool> stop_a_{false};
     int n_tasks_ = 0;
-    int active_ = 0;
+    int sleepers_ = 0;
     uint64_t epoch_ = 0;
     bool stop_ = false;
 };
 
 struct NodeA { float x, y, z, m; };               // centre of mass, mass
 struct NodeB { float w2; int32_t skip; float w; int32_t body; };  // width^2, skip, width, body id of a leaf or -1
+struct alignas(32) NodeRec { NodeA a; NodeB b; };  // one 32-byte record per node: a single s_load_dwordx8 on the device
 
 // Output arrays live in caller-chosen memory (the API hands in pinned-host allocators so the
 // H2D copy of the node array is a single DMA; tests use malloc).
 struct HostTree {
-    NodeA* a = nullptr;
-    NodeB* b = nullptr;
+    NodeRec* nodes = nullptr;
     int32_t* order = nullptr;  // body ids in depth-first leaf order
     size_t n_nodes = 0, n_order = 0;
     size_t cap_nodes = 0, cap_order = 0;
     bool too_deep = false;
     void* (*alloc)(size_t) = nullptr;  // null -> malloc/free
     void (*release)(void*) = nullptr;
-    void reserve(size_t nodes, size_t order_n);
+    void reserve(size_t n_nodes_wanted, size_t order_n);
     void clear();
     ~HostTree() { clear(); }
     HostTree() = default;
@@ -60,7 +63,17 @@ struct HostTree {
 // pos4: {x,y,z,m} records; the bodies are the concatenation of n_seg segments of seg_cap slots
 // holding count[s] live bodies each; a body's id is s*seg_cap + j.  Bodies enter the build in id
 // order, which is the reference's vector order.
+// working memory of the build, kept from step to step
+struct BuildScratch {
+    struct Impl;
+    Impl* impl;
+    BuildScratch();
+    ~BuildScratch();
+    BuildScratch(const BuildScratch&) = delete;
+    BuildScratch& operator=(const BuildScratch&) = delete;
+};
+
 void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, const float center[3], float width,
-                  WorkerPool& pool, HostTree& out);
+                  WorkerPool& pool, BuildScratch& scratch, HostTree& out);
 
 }  // namespace nbody

@@ -23,7 +23,7 @@ def same_tree(nb, orc, a, center, width, threads):
     return t
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 9, 64, 1000, 5000])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 9, 64, 1000, 5000, 8192, 20000])
 @pytest.mark.parametrize("threads", [1, 4])
 def test_tree_matches_oracle_plummer(nb, orc, n, threads):
     a = nb.plummer(n, seed=100 + n) if n else np.zeros(0, nb.PARTICLE_DTYPE)
