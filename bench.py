@@ -99,15 +99,18 @@ def main():
             sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    nb = graft.load_package()  # loads libnbody_hip.so (and /opt/rocm's HIP runtime) BEFORE torch
-    if nb.device_count() < 1:
-        sys.exit("bench.py needs a HIP device: the engine has no CPU fallback")
-
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "MASTER_PORT" in os.environ:  # launched by torch.distributed.run (any N)
+        # torch bundles its own ROCm runtime libraries under the same SONAMEs as /opt/rocm's; a
+        # process must end up with ONE set, so torch goes first and libnbody_hip.so binds to what is
+        # already loaded (the other order aborts at exit with a double free).  N = 1 never imports torch.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist  # control plane only (gloo)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    nb = graft.load_package()
+    if nb.device_count() < 1:
+        sys.exit("bench.py needs a HIP device: the engine has no CPU fallback")
 
     n = args.n
     box = ((0.0, 0.0, 0.0), 64.0)
@@ -120,7 +123,7 @@ def main():
     sim = nb.Simulation(ics, *box, method=method, math_mode=math_mode, capacity=n, device=local_rank,
                         rank=rank, world_size=world)
     sim.settings = nb.Settings(**st)
-    if world > 1:
+    if dist is not None:
         ident = [nb.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         sim.comm_init(ident[0])

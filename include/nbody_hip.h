@@ -159,6 +159,14 @@ int nbody_ic_plummer(void* aos, size_t n, size_t stride_bytes, uint64_t seed);
  * writes n+1 records. */
 int nbody_ic_disc(void* aos, size_t n_disc, size_t stride_bytes, uint64_t seed);
 
+/* ---- test hooks: one sharded step with the exchange done by the caller ------------------------- */
+/* G handles of one process (rank r of world G, same device) stand in for G GPUs: step_begin on
+ * each, import every peer's segment into each, step_end on each -- nbody_step_by with the RCCL
+ * all-gather replaced by device-to-device copies. */
+int nbody_debug_step_begin(NbodyHandle* h, float dt);
+int nbody_debug_import_segment(NbodyHandle* h, NbodyHandle* peer);
+int nbody_debug_step_end(NbodyHandle* h, float dt);
+
 /* ---- host-only entry (no device needed): the octree build alone ------------------------------ */
 /* BarnesHutSimulation::build_tree (barnes_hut.rs:143-183) + linearisation, as the Barnes-Hut step
  * runs it.  pos4 = n records {x,y,z,m}.  Output arrays hold `cap` nodes (com_mass: 4 floats per

@@ -54,6 +54,7 @@ DECLARED_SYMBOLS = [
     "nbody_sync", "nbody_set_profiling", "nbody_stats", "nbody_reset_stats", "nbody_energy", "nbody_tree_export",
     "nbody_last_error", "nbody_comm_unique_id", "nbody_comm_init", "nbody_local_range", "nbody_ic_plummer",
     "nbody_ic_disc", "nbody_host_build_tree", "nbody_abi_version", "nbody_device_count",
+    "nbody_debug_step_begin", "nbody_debug_import_segment", "nbody_debug_step_end",
 ]
 
 
@@ -116,6 +117,9 @@ _sig("nbody_ic_plummer", _i, C.c_void_p, _sz, _sz, C.c_uint64)
 _sig("nbody_ic_disc", _i, C.c_void_p, _sz, _sz, C.c_uint64)
 _sig("nbody_host_build_tree", _i, C.c_void_p, _sz, _pf, _f, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_void_p, _sz, C.POINTER(_sz))
+_sig("nbody_debug_step_begin", _i, _H, _f)
+_sig("nbody_debug_import_segment", _i, _H, _H)
+_sig("nbody_debug_step_end", _i, _H, _f)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
 
@@ -328,6 +332,21 @@ class Simulation:
     def comm_init(self, id_bytes: bytes):
         buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
         self._check(lib.nbody_comm_init(self._h, buf))
+
+
+def sharded_step(sims: list, dt: float | None = None):
+    """One step of a world of len(sims) shards living in this process (test harness: the exchange
+    the RCCL all-gather performs is done with device-to-device copies)."""
+    for s in sims:
+        d = s.settings.dt if dt is None else dt
+        s._check(lib.nbody_debug_step_begin(s._h, float(d)))
+    for s in sims:
+        for peer in sims:
+            if peer is not s:
+                s._check(lib.nbody_debug_import_segment(s._h, peer._h))
+    for s in sims:
+        d = s.settings.dt if dt is None else dt
+        s._check(lib.nbody_debug_step_end(s._h, float(d)))
 
 
 def comm_unique_id() -> bytes:

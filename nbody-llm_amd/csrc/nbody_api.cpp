@@ -169,7 +169,7 @@ size_t total_upper(const NbodyHandle* h) {
 // the once-per-step exchange of half-drifted positions: an in-place
 // all-gather of the own segment into every rank's pos_all, plus the live counts
 int exchange(NbodyHandle* h) {
-    if (h->sh.n_seg == 1) return NBODY_OK;
+    if (h->sh.n_seg == 1 && !h->comm_ready) return NBODY_OK;  // (a 1-rank communicator still runs the collective)
     if (!h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
     NCCL_TRY(h, ncclGroupStart());
     NCCL_TRY(h, ncclAllGather(h->sh.own_pos(), h->sh.pos_all, size_t(h->sh.seg_cap) * 4, ncclFloat, h->comm, h->stream));
@@ -342,21 +342,31 @@ int forces(NbodyHandle* h) {
     return h->cfg.method == NBODY_BARNES_HUT ? bh_forces(h) : bf_forces(h);
 }
 
-int step_impl(NbodyHandle* h, float dt) {
+int step_begin(NbodyHandle* h, float dt) {
     if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
-    Shard& sh = h->sh;
-    nbody::launch_drift_half(h->stream, sh, int(h->n_local), dt, h->bnd);  // integrate_pre_force
-    nbody::launch_compact(h->stream, sh);                                   // retain
+    nbody::launch_drift_half(h->stream, h->sh, int(h->n_local), dt, h->bnd);  // integrate_pre_force
+    nbody::launch_compact(h->stream, h->sh);                                   // retain
     h->count_dirty = true;
-    int rc = exchange(h);
-    if (rc) return rc;
-    rc = forces(h);                                                         // update_forces
-    if (rc) return rc;
-    nbody::launch_kick_drift(h->stream, sh, int(h->n_local), dt);           // integrate_after_force
     HIP_TRY(h, hipGetLastError());
-    h->elapsed += dt;                                                       // elapsed += dt
+    return NBODY_OK;
+}
+
+int step_end(NbodyHandle* h, float dt) {
+    int rc = forces(h);                                                        // update_forces
+    if (rc) return rc;
+    nbody::launch_kick_drift(h->stream, h->sh, int(h->n_local), dt);           // integrate_after_force
+    HIP_TRY(h, hipGetLastError());
+    h->elapsed += dt;                                                          // elapsed += dt
     h->stats.steps += 1;
     return NBODY_OK;
+}
+
+int step_impl(NbodyHandle* h, float dt) {
+    int rc = step_begin(h, dt);
+    if (rc) return rc;
+    rc = exchange(h);
+    if (rc) return rc;
+    return step_end(h, dt);
 }
 
 void free_all(NbodyHandle* h) {
@@ -796,6 +806,36 @@ int nbody_local_range(const NbodyHandle* h, size_t* first, size_t* count) {
     if (first) *first = h->first_global;
     if (count) *count = h->n_at_upload;
     return NBODY_OK;
+}
+
+// ---- test hooks: a sharded step with the exchange done by the caller --------------------------
+// Two handles of one process (ranks 0..G-1 of a world of G, all on the same device) can stand in
+// for G GPUs: step_begin on each, import every peer's segment into each, step_end on each.  This
+// is what nbody_step_by does around the RCCL all-gather; only the transport differs.
+int nbody_debug_step_begin(NbodyHandle* h, float dt) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    return rc ? rc : step_begin(h, dt);
+}
+
+int nbody_debug_import_segment(NbodyHandle* h, NbodyHandle* peer) {
+    if (!h || !peer) return NBODY_ERR_INVALID;
+    if (h->sh.n_seg != peer->sh.n_seg || h->sh.seg_cap != peer->sh.seg_cap) return fail(h, NBODY_ERR_INVALID, "peer has a different sharding");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int s = peer->sh.my_seg;
+    HIP_TRY(h, hipStreamSynchronize(peer->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sh.pos_all + size_t(s) * h->sh.seg_cap, peer->sh.own_pos(), size_t(h->sh.seg_cap) * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sh.seg_count + s, peer->sh.own_count(), sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->count_dirty = true;
+    return NBODY_OK;
+}
+
+int nbody_debug_step_end(NbodyHandle* h, float dt) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    return rc ? rc : step_end(h, dt);
 }
 
 // Host-only entry (no device needed): the octree build alone, for tests of the host logic.

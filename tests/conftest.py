@@ -17,8 +17,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def nb():
-    """The product: ctypes binding of libnbody_hip.so (loaded before anything imports torch, so the
-    process keeps /opt/rocm's HIP runtime, the one the code objects were built against)."""
+    """The product: ctypes binding of libnbody_hip.so.  The test process itself never imports torch
+    (torch bundles a second ROCm runtime; tests that need torch.distributed run it in child
+    processes that import torch first)."""
     return graft.load_package()
 
 

@@ -1,0 +1,38 @@
+"""The bench CLI that stands in for the reference's src/main.rs: same argv (`-t`, `-n`), same
+workload (disc, dt=3e-2, g_soft=0.02, theta2=1.0, Barnes-Hut), same two output lines that
+perf_benchmark.py's harness and the authors' notebook rely on."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "nbody-llm_amd", "nbody_cli")
+
+
+def test_cli_is_built_and_fails_loudly_without_a_device(nb):
+    assert os.path.exists(CLI), "run __graft_entry__.build()"
+    if nb.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    r = subprocess.run([CLI, "-t", "2", "-n", "100"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_cli_rejects_unknown_flags():
+    r = subprocess.run([CLI, "--bogus"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--method", "bf", "--ic", "plummer"]])
+def test_cli_reference_argv_and_output_lines(gpu, extra):
+    r = subprocess.run([CLI, "-t", "4", "-n", "3000", "--steps", "50"] + extra, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "Running simulation without rendering..." in out           # main.rs:111
+    assert re.search(r"^Elapsed: [0-9.]+s$", out, re.M)                # main.rs:125
+    m = re.search(r"^Performance: ([0-9.]+) steps/second$", out, re.M)  # main.rs:128
+    assert m and float(m.group(1)) > 1.0
+    left = int(re.search(r"Bodies left: (\d+)", out).group(1))
+    assert 2500 <= left <= 3001

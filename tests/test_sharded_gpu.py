@@ -1,0 +1,137 @@
+"""The multi-GPU path on ONE GPU: G handles of this process play ranks 0..G-1 of a world of G
+(same device); the per-step exchange that nbody_step_by does with an RCCL all-gather is done here
+with device-to-device copies (nbody_debug_* hooks).  Everything else is the production code:
+index-block shards, per-segment counts, the force kernels over segments, per-shard retain.
+Oracle of the sharded run = the 1-shard run (and the CPU oracle): strict math bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BOX = ((0.0, 0.0, 0.0), 64.0)
+FIELDS = ("position", "velocity", "acceleration", "mass")
+
+
+def make_world(nb, ics, G, box, st, method, math_mode):
+    sims = [nb.Simulation(ics, *box, method=method, math_mode=math_mode, rank=r, world_size=G, capacity=len(ics))
+            for r in range(G)]
+    for s in sims:
+        s.settings = st
+        s.init()
+    return sims
+
+
+def gather(sims):
+    return np.concatenate([s.get_points() for s in sims])
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_brute_force_strict_shards_match_single_and_oracle(gpu, orc, G):
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.0, dt=1e-3, theta2=0.5)
+    st = nb.Settings(**sd)
+    ics = nb.plummer(1000, seed=G)         # 1000 is not a multiple of 3 or 8: ragged last block
+    sims = make_world(nb, ics, G, BOX, st, nb.BRUTE_FORCE, nb.STRICT)
+    assert [s.local_range() for s in sims] == [(lo, hi - lo) for lo, hi in (nb.shard_range(1000, r, G) for r in range(G))]
+    for _ in range(5):
+        nb.sharded_step(sims)
+    got = gather(sims)
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(5):
+        ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], sd["dt"])
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    for s in sims:
+        s.close()
+
+
+def test_brute_force_shards_with_escapes(gpu, orc):
+    """Bodies leave a tight box on different shards at different steps: every shard compacts its
+    own block, the counts travel with the exchange, global order is preserved."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 1.5)
+    sd = dict(g=1.0, g_soft=0.05, dt=2e-2, theta2=0.5)
+    ics = nb.plummer(1500, seed=11)
+    sims = make_world(nb, ics, 4, box, nb.Settings(**sd), nb.BRUTE_FORCE, nb.STRICT)
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(10):
+        nb.sharded_step(sims)
+        ref = orc.bf_step_by(ref, sd, box[0], box[1], sd["dt"])
+    got = gather(sims)
+    assert len(ref) < 1400 and len(got) == len(ref)
+    assert sum(len(s) for s in sims) == sims[0].count_global() == len(ref)
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    for s in sims:
+        s.close()
+
+
+def test_brute_force_fast_shards(gpu, orc):
+    nb = gpu
+    sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
+    ics = nb.plummer(6000, seed=5)
+    sims = make_world(nb, ics, 2, BOX, nb.Settings(**sd), nb.BRUTE_FORCE, nb.FAST)
+    for _ in range(3):
+        nb.sharded_step(sims)
+    got = gather(sims)
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(3):
+        ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], sd["dt"])
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    assert rel_err(got["position"], ref["position"]) < 1e-6
+    for s in sims:
+        s.close()
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_barnes_hut_shards_match_single(gpu, orc, G):
+    """E2 option A: every shard builds the same global tree from the gathered positions and walks
+    it for its own bodies; counts add up to the 1-shard counts, state equals the oracle's."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(3000, seed=21)
+    sims = make_world(nb, ics, G, BOX, nb.Settings(**sd), nb.BARNES_HUT, nb.STRICT)
+    ref = ics.copy().astype(orc.P32)
+    tot_a = tot_v = 0
+    for _ in range(4):
+        nb.sharded_step(sims)
+        ref, a, v = orc.bh_step_by(ref, sd, BOX[0], BOX[1], sd["dt"], threads=4)
+        tot_a += a
+        tot_v += v
+    got = gather(sims)
+    stats = [s.stats() for s in sims]
+    assert sum(s.interactions for s in stats) == tot_a and sum(s.node_visits for s in stats) == tot_v
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    for s in sims:
+        s.close()
+
+
+def test_rccl_single_rank_communicator(gpu, orc):
+    """The RCCL code path itself (ncclGetUniqueId, ncclCommInitRank, grouped in-place all-gathers on
+    the handle's stream) with a world of one: results must not change."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.0, dt=1e-3, theta2=0.5)
+    ics = nb.plummer(777, seed=3)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.STRICT) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.comm_init(nb.comm_unique_id())
+        sim.steps(4)
+        got = sim.get_points()
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(4):
+        ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], sd["dt"])
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+
+
+def test_sharded_handle_without_communicator_fails_loudly(gpu):
+    nb = gpu
+    ics = nb.plummer(64)
+    with nb.Simulation(ics, *BOX, rank=0, world_size=2, capacity=64) as sim:
+        with pytest.raises(nb.NbodyError) as e:
+            sim.step()
+        assert e.value.code == nb.NBODY_ERR_COMM
+        with pytest.raises(nb.NbodyError):
+            sim.add_point(ics[0])
