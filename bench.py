@@ -55,8 +55,9 @@ def cpu_baseline(orc, ics, settings, box, workload):
     center, width = box
     n = len(ics)
     if workload == "bf":
-        # the reference loop is serial (brute_force.rs:70-81): one thread, first 24 576 bodies
-        m = min(n, 24576)
+        # the reference loop is serial (brute_force.rs:70-81): one thread, one pass over all bodies
+        # (~9 s at N = 65 536); larger N are cut to 65 536 bodies
+        m = min(n, 65536)
         a = ics[:m].astype(orc.P32)
         t0 = time.perf_counter()
         orc.bf_update_forces(a, settings)

@@ -111,7 +111,12 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
                                                      int A, int K, const int* __restrict__ bounds, int sym_sets,
                                                      float4* __restrict__ planes, size_t plane_stride, float eps2) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * WPB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // global wave index
+    // Slices of a set differ by one chunk (e.g. 15,16,16,16,15,...).  A workgroup's waves land on the
+    // SIMDs cyclically (wave w on SIMD w % 4, observed via HW_ID), so slices are dealt such that each
+    // SIMD gets WPB/4 CONSECUTIVE slices -- one short one and the long ones -- and all four SIMDs of
+    // the CU carry the same number of chunks.
+    const int wslot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * WPB + (wslot & 3) * (WPB / 4) + (wslot >> 2);  // global slice index
     if (gw >= A * K) return;
     const int a = gw / K;                        // resident set
     const int part = gw - a * K;                 // this wave's slice of the set's chunk sequence
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(512) void k_bf_sym_rest(const float4* __restrict__ 
         if (set >= A) set -= A;
         const int j0 = set * SET + wv * SLICE;
         const int j1 = min(n, j0 + SLICE);
+#pragma unroll 8
         for (int j = j0; j < j1; ++j) {
             const float4 pj = pos[j];  // wave-uniform address
             const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
@@ -255,8 +261,10 @@ __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict_
 }  // namespace nbody
 namespace nbody { int read_sym_stamps(unsigned long long* out, int n_waves); }
 extern "C" int nbody_sym_read_stamps(unsigned long long* out, int n_waves) { return nbody::read_sym_stamps(out, n_waves); }
-extern "C" int nbody_sym_waves_per_simd = 4;
-extern "C" int nbody_sym_debug = 0;  // 4: diagnostic build with in-kernel cycle stamps  // tuning hook (NBODY_SYM_WAVES environment variable)
+extern "C" int nbody_sym_waves_per_simd = 4;  // (unused; older tuning scripts set it)
+extern "C" int nbody_sym_wpb = 12;     // waves per workgroup: 16, 12 or 8   (tuning hooks, tools/tune_sym.py)
+extern "C" int nbody_sym_rounds = 1;   // rounds of workgroups per CU
+extern "C" int nbody_sym_debug = 0;    // 4: diagnostic build with in-kernel cycle stamps
 namespace nbody {
 
 // ----------------------------------------------------------------------------------- host side
@@ -267,12 +275,14 @@ SymPlan make_sym_plan(int n_upper) {
     p.A = (n_upper + 64 * IPT - 1) / (64 * IPT);
     p.sym_sets = (p.A + 1) / 2 - 1;             // ceil(A/2) - 1 sets are met symmetrically
     const int L = IPT * p.sym_sets;              // chunk visits per set, all of equal cost
-    // waves per set: at most 1024 * waves_per_simd waves in all, so that every workgroup is resident
-    // at once, one (or two) per CU; the unused fraction of the last CU's slots is the only imbalance
-    p.wpb = (nbody_sym_waves_per_simd >= 6) ? 12 : 16;
-    const int slots = (p.wpb == 12) ? 6144 : 4096;
+    // waves per set: every workgroup is CU-sized (wpb waves; the register budget admits 4 waves per
+    // SIMD), so the grid is dealt evenly; `rounds` > 1 makes shorter waves in several rounds, which
+    // trims the tail at the price of more resident-side planes
+    p.wpb = nbody_sym_wpb == 8 ? 8 : nbody_sym_wpb == 12 ? 12 : 16;
+    const int resident_wgs_per_cu = (p.wpb == 8) ? 2 : 1;
+    const int slots = 256 * resident_wgs_per_cu * p.wpb * std::max(1, nbody_sym_rounds);
     int K = slots / p.A;
-    if (K > 96) K = 96;
+    if (K > 126) K = 126;
     if (K > L) K = L;
     if (K < 1) K = 1;
     p.K = K;
@@ -303,12 +313,12 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
     const dim3 grid((p.A * p.K + p.wpb - 1) / p.wpb), block(p.wpb * 64);
 #define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.n_pad, g_soft2)
     if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
-        if (p.wpb == 12) SYM_LAUNCH(12, 4); else SYM_LAUNCH(16, 4);
+        if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
     } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
     } else if (nbody_sym_debug == 6) { SYM_LAUNCH(16, 6);
     } else if (nbody_sym_debug == 7) { SYM_LAUNCH(16, 7);
     } else {
-        if (p.wpb == 12) SYM_LAUNCH(12, 0); else SYM_LAUNCH(16, 0);
+        if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
     }
 #undef SYM_LAUNCH
 }

@@ -24,6 +24,8 @@
 
 extern "C" int nbody_bf_fast_variant;
 extern "C" int nbody_sym_waves_per_simd;
+extern "C" int nbody_sym_wpb;
+extern "C" int nbody_sym_rounds;
 
 using nbody::BoundsF;
 using nbody::Shard;
@@ -216,8 +218,9 @@ constexpr size_t kSymMinBodies = 8192;
 // (re)build the symmetric kernel's plan when the number of resident sets changes
 int ensure_sym_plan(NbodyHandle* h) {
     const int A = int((h->n_local + 511) / 512);
-    if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == nbody_sym_waves_per_simd) return NBODY_OK;
-    h->sym_waves = nbody_sym_waves_per_simd;
+    const int knobs = nbody_sym_wpb * 100 + nbody_sym_rounds;
+    if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == knobs) return NBODY_OK;
+    h->sym_waves = knobs;
     h->sym_plan = nbody::make_sym_plan(int(h->n_local));
     const nbody::SymPlan& p = h->sym_plan;
     if (!h->d_sym_bounds) HIP_TRY(h, hipMalloc(&h->d_sym_bounds, 128 * sizeof(int)));

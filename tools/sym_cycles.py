@@ -31,5 +31,5 @@ for w, dv in [(w, d) for w in wps_list for d in dbg_list]:
     ghz = st[:, 0] / st[:, 1] * 0.1
     print(f"dbg {dv} waves/SIMD {w}: waves {nw}, chunks/wave {st[:,2].min():.0f}-{st[:,2].max():.0f}, "
           f"cycles per 8-pair step: median {np.median(cyc_per_step):.1f} (min {cyc_per_step.min():.1f}, max {cyc_per_step.max():.1f}); "
-          f"clock median {np.median(ghz):.3f} GHz; wave lifetime median {np.median(st[:,1])/100:.1f} us max {st[:,1].max()/100:.1f} us")
+          f"clock median {np.median(ghz):.3f} GHz; wave lifetime min {st[:,1].min()/100:.1f} median {np.median(st[:,1])/100:.1f} us max {st[:,1].max()/100:.1f} us")
 dbg.value = 0
