@@ -51,7 +51,8 @@ struct SymPlan {
     int K = 0;            // waves per resident set
     int wpb = 16;         // waves per workgroup (16: one workgroup per CU, 12: two)
     int sym_sets = 0;     // sets met symmetrically = ceil(A/2) - 1
-    int n_planes = 0;     // partial-sum planes
+    int n_planes = 0;     // partial-sum planes (own-shard kernels + k_os one-sided planes of a sharded run)
+    int k_os = 0;         // slices per resident set of the one-sided remote kernel (0 = single shard)
     size_t n_pad = 0;     // bodies per plane (A * 64 * ipt)
     std::vector<int> bounds;  // K+1 cut points of a set's chunk sequence
 };
@@ -59,6 +60,7 @@ SymPlan make_sym_plan(int n_upper);
 uint64_t sym_main_pairs(const SymPlan& p, size_t n);  // unordered pairs of real bodies k_bf_sym evaluates
 void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
                         int n_upper, float g_soft2);
+void launch_bf_os(hipStream_t s, const Shard& sh, int A, int K, float4* planes, size_t plane_stride, float g_soft2);
 void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4* planes, int n_upper, float g,
                         float g_soft2);
 

@@ -46,7 +46,7 @@ __device__ unsigned long long nbody_sym_stamps[3 * 8192];  // diagnostic builds 
 // that every instruction's inputs were produced at least IPT instructions earlier (the compiler's
 // own schedule chains dependent fma -> rsq -> mul -> fma back to back and issues at ~4 cycles per
 // instruction instead of ~2.3; sched_barrier keeps the stages in this order).
-template <int IPT, int DBG = 0>
+template <int IPT, int DBG = 0, bool SYM = true>
 __device__ __forceinline__ void pair_evals(const float (&xi)[IPT], const float (&yi)[IPT], const float (&zi)[IPT],
                                            const float (&mi)[IPT], float (&axi)[IPT], float (&ayi)[IPT],
                                            float (&azi)[IPT], float xj, float yj, float zj, float mj, float& axj,
@@ -85,17 +85,29 @@ __device__ __forceinline__ void pair_evals(const float (&xi)[IPT], const float (
 #pragma unroll
     for (int q = 0; q < IPT; ++q) sj[q] = mj * r[q];     // what body j does to body i
     __builtin_amdgcn_sched_barrier(0);
+    if (SYM) {
 #pragma unroll
-    for (int q = 0; q < IPT; ++q) r[q] = mi[q] * r[q];   // what body i does to body j
-    __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < IPT; ++q) r[q] = mi[q] * r[q];   // what body i does to body j
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < IPT; ++q) {
-        axi[q] = __builtin_fmaf(dx[q], sj[q], axi[q]);
-        axj = __builtin_fmaf(-dx[q], r[q], axj);
-        ayi[q] = __builtin_fmaf(dy[q], sj[q], ayi[q]);
-        ayj = __builtin_fmaf(-dy[q], r[q], ayj);
-        azi[q] = __builtin_fmaf(dz[q], sj[q], azi[q]);
-        azj = __builtin_fmaf(-dz[q], r[q], azj);
+        for (int q = 0; q < IPT; ++q) {
+            axi[q] = __builtin_fmaf(dx[q], sj[q], axi[q]);
+            axj = __builtin_fmaf(-dx[q], r[q], axj);
+            ayi[q] = __builtin_fmaf(dy[q], sj[q], ayi[q]);
+            ayj = __builtin_fmaf(-dy[q], r[q], ayj);
+            azi[q] = __builtin_fmaf(dz[q], sj[q], azi[q]);
+            azj = __builtin_fmaf(-dz[q], r[q], azj);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {  // one-sided: only the resident bodies are updated
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) axi[q] = __builtin_fmaf(dx[q], sj[q], axi[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) ayi[q] = __builtin_fmaf(dy[q], sj[q], ayi[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) azi[q] = __builtin_fmaf(dz[q], sj[q], azi[q]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -197,6 +209,84 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
     }
     // resident side: one plane per slice index
     float4* __restrict__ out = planes + size_t(sym_sets + part) * plane_stride;
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) out[size_t(a * IPT + q) * 64 + lane] = make_float4(axi[q], ayi[q], azi[q], 0.f);
+}
+
+// One-sided companion for sharded runs: the bodies of OTHER shards exert forces on the own bodies
+// but their accelerations belong to their own GPU, so nothing is gained by updating both sides.
+// Same skeleton as k_bf_sym -- a resident set of 64*IPT own bodies per wave in registers, CU-sized
+// workgroups, stage-ordered evaluation -- but the partners are a contiguous slice of the
+// concatenated remote segments, staged 64 at a time in the wave's private LDS tile and read back
+// as wave-uniform broadcasts (ds_read_b128), 12 VALU + 1 v_rsq_f32 per interaction.  Slices are cut
+// to the body (not to the chunk), so all waves carry the same number of partners.  Output: one
+// resident-side plane per slice (added by k_bf_sym_reduce with the others).
+template <int IPT, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_bf_os(const float4* __restrict__ pos_all,
+                                                    const int* __restrict__ seg_count, int n_seg, int seg_cap,
+                                                    int my_seg, int A, int K, float4* __restrict__ planes,
+                                                    size_t plane_stride, float eps2) {
+    __shared__ float4 stage[WPB][2][64];
+    const int lane = threadIdx.x & 63;
+    const int wslot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * WPB + (wslot & 3) * (WPB / 4) + (wslot >> 2);
+    if (gw >= A * K) return;
+    const int a = gw / K, part = gw - a * K;
+    const int n_own = seg_count[my_seg];
+    const float4* __restrict__ own = pos_all + size_t(my_seg) * seg_cap;
+    float eps2v = eps2;
+    asm volatile("" : "+v"(eps2v));
+
+    float xi[IPT], yi[IPT], zi[IPT], mi[IPT], axi[IPT], ayi[IPT], azi[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        const int i = (a * IPT + q) * 64 + lane;
+        const float4 p = (i < n_own) ? own[i] : make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
+        xi[q] = p.x; yi[q] = p.y; zi[q] = p.z; mi[q] = p.w;
+        axi[q] = ayi[q] = azi[q] = 0.f;
+    }
+    // this wave's slice [r0, r1) of the remote bodies (all segments but the own one, in order)
+    long long R = 0;
+    for (int s = 0; s < n_seg; ++s) if (s != my_seg) R += seg_count[s];
+    const long long r0 = R * part / K, r1 = R * (part + 1) / K;
+    long long seg_first = 0;  // remote index of the current segment's first body
+    float dummy_x = 0.f, dummy_y = 0.f, dummy_z = 0.f;  // pair_evals' travelling-side accumulators (unused)
+    for (int s = 0; s < n_seg; ++s) {
+        if (s == my_seg) continue;
+        const int ns = seg_count[s];
+        const long long lo = r0 > seg_first ? r0 : seg_first;
+        const long long hi = r1 < seg_first + ns ? r1 : seg_first + ns;
+        const float4* __restrict__ ps = pos_all + size_t(s) * seg_cap - seg_first;  // indexable by remote index
+        int buf = 0;
+        if (lo < hi) {
+            const long long j = lo + lane;
+            stage[wslot][0][lane] = (j < hi) ? ps[j] : make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
+        }
+        for (long long c0 = lo; c0 < hi; c0 += 64) {
+            const long long jn = c0 + 64 + lane;  // next tile, fetched while this one is consumed
+            float4 nxt = make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
+            if (c0 + 64 < hi && jn < hi) nxt = ps[jn];
+            const int cnt = int(hi - c0 < 64 ? hi - c0 : 64);
+            // priority = quarter of the slice still to do (see k_bf_sym): the waves of a SIMD finish together
+            switch (int((4 * (r1 - c0) - 1) / (r1 - r0))) {
+                case 3: __builtin_amdgcn_s_setprio(3); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+            }
+            float4 pj = stage[wslot][buf][0];  // wave-uniform address: LDS broadcast
+            for (int t = 0; t < cnt; ++t) {
+                const float4 pn = stage[wslot][buf][(t + 1) & 63];  // the next partner lands behind this one's math
+                pair_evals<IPT, 0, false>(xi, yi, zi, mi, axi, ayi, azi, pj.x, pj.y, pj.z, pj.w, dummy_x, dummy_y,
+                                          dummy_z, eps2v);
+                pj = pn;
+            }
+            buf ^= 1;
+            stage[wslot][buf][lane] = nxt;  // same wave writes and reads its tile: program order suffices
+        }
+        seg_first += ns;
+    }
+    float4* __restrict__ out = planes + size_t(part) * plane_stride;
 #pragma unroll
     for (int q = 0; q < IPT; ++q) out[size_t(a * IPT + q) * 64 + lane] = make_float4(axi[q], ayi[q], azi[q], 0.f);
 }
@@ -323,6 +413,14 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
 #undef SYM_LAUNCH
 }
 
+// one-sided forces of the other shards' bodies on the own bodies: K_os planes starting at `planes`
+void launch_bf_os(hipStream_t s, const Shard& sh, int A, int K, float4* planes, size_t plane_stride, float g_soft2) {
+    if (A <= 0 || K <= 0) return;
+    const int wpb = 12;
+    hipLaunchKernelGGL((k_bf_os<8, 12>), dim3((A * K + wpb - 1) / wpb), dim3(wpb * 64), 0, s, sh.pos_all, sh.seg_count,
+                       sh.n_seg, sh.seg_cap, sh.my_seg, A, K, planes, plane_stride, g_soft2);
+}
+
 // own/opposite-set pairs + the fixed-order sum of the planes into acc
 void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4* planes, int n_upper, float g,
                         float g_soft2) {
@@ -331,7 +429,7 @@ void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4
     if (p.sym_sets == 0)  // no symmetric pass: the resident-side planes are never written
         (void)hipMemsetAsync(resident0, 0, size_t(p.K) * p.n_pad * sizeof(float4), s);
     hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(), sh.own_count(), p.A,
-                       planes + size_t(p.n_planes - 1) * p.n_pad, g_soft2);
+                       planes + size_t(p.sym_sets + p.K) * p.n_pad, g_soft2);
     hipLaunchKernelGGL(k_bf_sym_reduce, dim3((n_upper + 255) / 256), dim3(256), 0, s, planes, p.n_planes, p.n_pad,
                        sh.own_count(), g, sh.acc);
 }

@@ -213,7 +213,8 @@ int drain_events(NbodyHandle* h) {
     return NBODY_OK;
 }
 
-constexpr size_t kSymMinBodies = 8192;
+constexpr size_t kSymMinBodies = 8192;       // single shard: below this the LDS-tiled one-sided kernel is used
+constexpr size_t kShardedSymMinBodies = 2048; // sharded: own-own symmetric + remote one-sided from this size up
 
 // (re)build the symmetric kernel's plan when the number of resident sets changes
 int ensure_sym_plan(NbodyHandle* h) {
@@ -222,7 +223,11 @@ int ensure_sym_plan(NbodyHandle* h) {
     if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == knobs) return NBODY_OK;
     h->sym_waves = knobs;
     h->sym_plan = nbody::make_sym_plan(int(h->n_local));
-    const nbody::SymPlan& p = h->sym_plan;
+    nbody::SymPlan& p = h->sym_plan;
+    if (h->sh.n_seg > 1) {  // one-sided planes for the other shards' bodies: CU-sized 12-wave workgroups
+        p.k_os = std::max(1, std::min(256, 3072 / p.A));
+        p.n_planes += p.k_os;
+    }
     if (!h->d_sym_bounds) HIP_TRY(h, hipMalloc(&h->d_sym_bounds, 128 * sizeof(int)));
     HIP_TRY(h, hipMemcpyAsync(h->d_sym_bounds, p.bounds.data(), p.bounds.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // p.bounds is pageable
@@ -238,29 +243,46 @@ int ensure_sym_plan(NbodyHandle* h) {
 
 int bf_forces(NbodyHandle* h) {
     const float eps2 = h->g_soft * h->g_soft;  // brute_force.rs:69
-    const bool sym = h->cfg.math_mode == NBODY_MATH_FAST && h->sh.n_seg == 1 && h->n_local >= kSymMinBodies &&
-                     nbody_bf_fast_variant == 0;
+    const bool fast = h->cfg.math_mode == NBODY_MATH_FAST && nbody_bf_fast_variant == 0;
+    const bool sharded = h->sh.n_seg > 1;
+    const bool sym = fast && h->n_local >= (sharded ? kShardedSymMinBodies : kSymMinBodies);
+    const size_t tot = total_upper(h);
     if (sym) {
         int rc = ensure_sym_plan(h);
         if (rc) return rc;
+        if (h->sym_pairs_n != h->n_local) {
+            h->sym_pairs = nbody::sym_main_pairs(h->sym_plan, h->n_local);
+            h->sym_pairs_n = h->n_local;
+        }
     }
-    if (sym && h->sym_pairs_n != h->n_local) {
-        h->sym_pairs = nbody::sym_main_pairs(h->sym_plan, h->n_local);
-        h->sym_pairs_n = h->n_local;
-    }
-    {
-        ForceTimer t(h);  // HIP events around the dominant launch only
+    const nbody::SymPlan& p = h->sym_plan;
+    uint64_t timed = 0;  // interactions of the launch the HIP events bracket (the dominant one)
+    if (!sym) {
+        ForceTimer t(h);
         if (h->cfg.math_mode == NBODY_MATH_STRICT) nbody::launch_bf_forces_strict(h->stream, h->sh, int(h->n_local), h->g, eps2);
-        else if (sym) nbody::launch_bf_sym_main(h->stream, h->sh, h->sym_plan, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
         else nbody::launch_bf_forces_fast(h->stream, h->sh, int(h->n_local), h->g, eps2);
+        timed = tot > 0 ? uint64_t(h->n_local) * uint64_t(tot - 1) : 0;
+    } else if (!sharded) {
+        {
+            ForceTimer t(h);
+            nbody::launch_bf_sym_main(h->stream, h->sh, p, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
+        }
+        timed = 2 * h->sym_pairs;
+        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2);
+    } else {
+        // own shard symmetric, the other shards one-sided, one fixed-order sum over all the planes
+        nbody::launch_bf_sym_main(h->stream, h->sh, p, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
+        {
+            ForceTimer t(h);
+            nbody::launch_bf_os(h->stream, h->sh, p.A, p.k_os, h->d_planes + size_t(p.n_planes - p.k_os) * p.n_pad, p.n_pad, eps2);
+        }
+        timed = uint64_t(h->n_local) * uint64_t(tot - h->n_local);
+        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2);
     }
-    if (sym) nbody::launch_bf_sym_tail(h->stream, h->sh, h->sym_plan, h->d_planes, int(h->n_local), h->g, eps2);
     HIP_TRY(h, hipGetLastError());
-    size_t tot = total_upper(h);
     if (tot > 0) {
-        const uint64_t all = uint64_t(h->n_local) * uint64_t(tot - 1);
-        h->stats.interactions += all;
-        if (h->profiling) h->stats.force_kernel_interactions += sym ? 2 * h->sym_pairs : all;
+        h->stats.interactions += uint64_t(h->n_local) * uint64_t(tot - 1);
+        if (h->profiling) h->stats.force_kernel_interactions += timed;
     }
     return NBODY_OK;
 }

@@ -67,19 +67,48 @@ def test_brute_force_shards_with_escapes(gpu, orc):
         s.close()
 
 
-def test_brute_force_fast_shards(gpu, orc):
+@pytest.mark.parametrize("G,n", [(2, 6000), (2, 20000), (3, 10000), (8, 20000), (8, 65536)])
+def test_brute_force_fast_shards(gpu, orc, G, n):
+    """fast math, sharded: the own shard by the symmetric kernel, the other shards by the one-sided
+    kernel k_bf_os (n/G >= 2048), else the LDS-tiled kernel; 1e-5 against the f32 oracle."""
     nb = gpu
     sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
-    ics = nb.plummer(6000, seed=5)
-    sims = make_world(nb, ics, 2, BOX, nb.Settings(**sd), nb.BRUTE_FORCE, nb.FAST)
-    for _ in range(3):
+    ics = nb.plummer(n, seed=5)
+    ics["mass"] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
+    sims = make_world(nb, ics, G, BOX, nb.Settings(**sd), nb.BRUTE_FORCE, nb.FAST)
+    steps = 2 if n <= 20000 else 1
+    for _ in range(steps):
         nb.sharded_step(sims)
     got = gather(sims)
     ref = ics.copy().astype(orc.P32)
-    for _ in range(3):
-        ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], sd["dt"])
-    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    for k in range(steps):
+        if n <= 20000:
+            ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], sd["dt"])
+        else:  # the serial reference loop is too slow here: same step with the threaded row-wise form
+            orc.pre_force(ref, sd["dt"])
+            orc.bf_update_forces_rows(ref, sd, threads=16)
+            orc.after_force(ref, sd["dt"])
+    assert np.isfinite(got["acceleration"]).all()
+    assert rel_err(got["acceleration"], ref["acceleration"]) < (1e-5 if n <= 20000 else 3e-5)
     assert rel_err(got["position"], ref["position"]) < 1e-6
+    for s in sims:
+        s.close()
+
+
+def test_brute_force_fast_shards_with_escapes(gpu, orc):
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 3.0)
+    sd = dict(g=1.0, g_soft=0.05, dt=2e-2, theta2=0.5)
+    ics = nb.plummer(12000, seed=12)
+    sims = make_world(nb, ics, 3, box, nb.Settings(**sd), nb.BRUTE_FORCE, nb.FAST)
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(8):
+        nb.sharded_step(sims)
+        ref = orc.bf_step_by(ref, sd, box[0], box[1], sd["dt"])
+    got = gather(sims)
+    assert len(ref) < 11500 and len(got) == len(ref)
+    assert np.array_equal(got["mass"], ref["mass"])
+    assert rel_err(got["position"], ref["position"]) < 1e-5
     for s in sims:
         s.close()
 
