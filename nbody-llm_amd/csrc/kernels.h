@@ -70,6 +70,13 @@ struct TreeDev {
     int n_nodes = 0;
     const int* order = nullptr;      // own bodies (index into the own segment) in tree order
     int n_order = 0;
+    // node-range split of the walk (kernels_bh.hip WalkSplit); n_split = 1: none
+    int n_split = 1;
+    const int* split_first = nullptr;   // [n_split + 1]
+    const int* split_anc = nullptr;     // [n_split][192]
+    const int* split_n_anc = nullptr;   // [n_split]
+    float4* split_planes = nullptr;     // [n_split][split_stride]
+    size_t split_stride = 0;
 };
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters /* [2]: accepted, visited */);

@@ -25,20 +25,55 @@ constexpr int kWalkBlock = 256;
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 struct alignas(32) NodeDev { float4 a; float4 b; };  // {com, mass}, {width^2, skip bits, width, leaf body}
 
+// The node index range [0, n_nodes) can be cut into n_seg contiguous segments walked by different
+// waves (more waves in flight: at N = 65 536 one wave per 64 bodies is only one wave per SIMD and the
+// walk is bound by the latency of its dependent node loads).  A body's walk enters segment k at the
+// first node >= first[k] that it would visit: to know, replay the opening tests of the ancestors of
+// node first[k] (root first; the host lists them, at most NBODY_MAX_TREE_DEPTH): an accepted
+// ancestor's skip link is where the walk resumes.  Ancestors are only tested here -- they are
+// counted and accumulated by the segment that contains them -- so every (body, node) pair is
+// evaluated by exactly one segment and the counters stay exact.
+struct WalkSplit {
+    int n_seg;
+    const int* first;        // [n_seg + 1] node index where each segment starts; first[n_seg] = n_nodes
+    const int* anc;          // [n_seg][kMaxAnc] ancestors of first[k], root first
+    const int* n_anc;        // [n_seg]
+    float4* planes;          // [n_seg][plane_stride] partial accelerations (n_seg > 1)
+    size_t plane_stride;
+};
+constexpr int kMaxAnc = 192;
+
+__device__ __forceinline__ int walk_entry(const NodeDev* __restrict__ nodes, const WalkSplit& sp, int seg,
+                                          const float4 p, float theta2) {
+    const int s0 = sp.first[seg];
+    const int na = sp.n_anc[seg];
+    for (int k = 0; k < na; ++k) {
+        const int j = sp.anc[seg * kMaxAnc + k];
+        const float4 A = nodes[j].a;
+        const float4 B = nodes[j].b;
+        const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;
+        const float r2 = (rx * rx + ry * ry) + rz * rz;
+        if (B.x < theta2 * r2) return __float_as_int(B.y);  // accepted: the walk resumes after its subtree
+    }
+    return s0;  // every ancestor was opened: the walk arrives at first[seg] itself
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restrict__ nodes, int n_nodes,
                                                         const int* __restrict__ order, int n_order,
                                                         const float4* __restrict__ own_pos, float4* __restrict__ acc,
                                                         float g, float eps2, float theta2,
-                                                        unsigned long long* __restrict__ counters) {
+                                                        unsigned long long* __restrict__ counters, WalkSplit split) {
     const int t = blockIdx.x * kWalkBlock + threadIdx.x;
+    const int seg = blockIdx.y;
+    const int s1 = split.first[seg + 1];
     unsigned int n_acc = 0, n_vis = 0;
     if (t < n_order) {
         const int b = order[t];
         const float4 p = own_pos[b];
         float ax = 0.f, ay = 0.f, az = 0.f;
-        int i = 0;
-        while (i < n_nodes) {
+        int i = walk_entry(nodes, split, seg, p, theta2);  // first node >= s0 this body's walk visits
+        while (i < s1) {
             const float4 A = nodes[i].a;
             const float4 B = nodes[i].b;
             const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
@@ -61,7 +96,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
                 i = i + 1;
             }
         }
-        acc[b] = make_float4(ax, ay, az, 0.f);                                  // overwrite, :260
+        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
     }
     // one atomic pair per wave
     for (int off = 32; off > 0; off >>= 1) {
@@ -90,16 +125,20 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
                                                              const int* __restrict__ order, int n_order,
                                                              const float4* __restrict__ own_pos,
                                                              float4* __restrict__ acc, float g, float eps2,
-                                                             float theta2, unsigned long long* __restrict__ counters) {
+                                                             float theta2, unsigned long long* __restrict__ counters,
+                                                             WalkSplit split) {
     const int t = blockIdx.x * kWalkBlock + threadIdx.x;
+    const int seg = blockIdx.y;
+    const int s0 = split.first[seg], s1 = split.first[seg + 1];
     const bool live = t < n_order;
     const int b = live ? order[t] : 0;
     const float4 p = live ? own_pos[b] : make_float4(0.f, 0.f, 0.f, 0.f);
     float ax = 0.f, ay = 0.f, az = 0.f;
     unsigned int n_acc = 0, n_vis = 0;
-    int resume = live ? 0 : 0x7fffffff;  // dead lanes never look at a node
-    int i = 0;                           // wave-uniform node index
-    while (i < n_nodes) {
+    // dead lanes never look at a node; live ones start where their own walk enters this segment
+    int resume = live ? walk_entry(nodes, split, seg, p, theta2) : 0x7fffffff;
+    int i = s0;                          // wave-uniform node index
+    while (i < s1) {
         // uniform address: ONE 32-byte scalar load (left to itself the compiler fetches the mass in a
         // third, dependent s_load under the accept branch)
         f32x8 rec;
@@ -128,7 +167,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
         const bool wants_children = active && !accept;
         i = __builtin_amdgcn_readfirstlane(__ballot(wants_children) != 0ull ? i + 1 : __float_as_int(B.y));
     }
-    if (live) acc[b] = make_float4(ax, ay, az, 0.f);                        // overwrite, :260
+    if (live) (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
     for (int off = 32; off > 0; off >>= 1) {
         n_acc += __shfl_down(n_acc, off);
         n_vis += __shfl_down(n_vis, off);
@@ -140,17 +179,38 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
 }
 
 }  // namespace nbody
+extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group: 0 = automatic
 extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative
 namespace nbody {
+
+__global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ planes, int n_seg, size_t plane_stride,
+                                                   const int* __restrict__ order, int n_order,
+                                                   float4* __restrict__ acc) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_order) return;
+    const int b = order[t];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = 0; k < n_seg; ++k) {  // segment order = the order the single walk adds them in
+        const float4 v = planes[size_t(k) * plane_stride + b];
+        sx += v.x; sy += v.y; sz += v.z;
+    }
+    acc[b] = make_float4(sx, sy, sz, 0.f);
+}
 
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters) {
     if (t.n_order <= 0) return;
-    int blocks = (t.n_order + kWalkBlock - 1) / kWalkBlock;
-#define WALK(K, F) hipLaunchKernelGGL(K<F>, dim3(blocks), dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters)
+    WalkSplit sp;
+    sp.n_seg = t.n_split; sp.first = t.split_first; sp.anc = t.split_anc; sp.n_anc = t.split_n_anc;
+    sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
+    dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
+#define WALK(K, F) hipLaunchKernelGGL(K<F>, grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
     if (nbody_bh_walk_variant == 1) { if (fast_math) WALK(k_bh_walk_wave, true); else WALK(k_bh_walk_wave, false); }
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
+    if (t.n_split > 1)
+        hipLaunchKernelGGL(k_bh_reduce, dim3((t.n_order + 255) / 256), dim3(256), 0, s, t.split_planes, t.n_split,
+                           t.split_stride, t.order, t.n_order, sh.acc);
 }
 
 }  // namespace nbody

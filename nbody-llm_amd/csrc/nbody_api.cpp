@@ -26,6 +26,7 @@ extern "C" int nbody_bf_fast_variant;
 extern "C" int nbody_sym_waves_per_simd;
 extern "C" int nbody_sym_wpb;
 extern "C" int nbody_sym_rounds;
+extern "C" int nbody_bh_walk_split;
 
 using nbody::BoundsF;
 using nbody::Shard;
@@ -61,6 +62,10 @@ struct NbodyHandle {
     float* h_pos = nullptr;    // pinned: all segments' positions
     int* h_counts = nullptr;   // pinned: all segments' counts
     std::vector<int32_t> own_order;
+    int* d_split = nullptr;      // [33 + 32 + 32*192] ints: first[], n_anc[], anc[][192]
+    int* h_split = nullptr;      // pinned mirror
+    float4* d_walk_planes = nullptr;
+    size_t walk_planes_cap = 0;  // float4 entries
     unsigned long long* d_counters = nullptr;  // [2] accepted, visited
     unsigned long long* h_counters = nullptr;  // pinned
 
@@ -354,6 +359,63 @@ int bh_forces(NbodyHandle* h) {
     nbody::TreeDev td;
     td.nodes = h->d_nodes; td.n_nodes = int(h->tree.n_nodes);
     td.order = h->d_order; td.n_order = int(n_order);
+    // split the node range over several waves per body group when there are too few bodies to fill
+    // the chip (>= 8 waves per SIMD wanted: the walk is bound by the latency of dependent loads)
+    {
+        constexpr int kMaxSplit = 32, kMaxAnc = 192;
+        int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((8192 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+        K = std::max(1, std::min(kMaxSplit, K));
+        if (size_t(K) * 64 > h->tree.n_nodes) K = 1;
+        if (K > 1) {
+            if (!h->d_split) {
+                HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
+                HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
+            }
+            int* first = h->h_split;
+            int* n_anc = first + kMaxSplit + 1;
+            int* anc = n_anc + kMaxSplit;
+            const nbody::NodeRec* nd = h->tree.nodes;
+            const int nn = int(h->tree.n_nodes);
+            for (int k = 0; k <= K; ++k) first[k] = int((long long)nn * k / K);
+            for (int k = 0; k < K; ++k) {  // ancestors of first[k]: walk down from the root along the skip links
+                int cnt = 0, j = 0;
+                const int target = first[k];
+                while (j != target && cnt < kMaxAnc) {
+                    anc[k * kMaxAnc + cnt++] = j;          // j < target < skip(j): an ancestor
+                    int c = j + 1;                         // its first child
+                    while (nd[c].b.skip <= target) c = nd[c].b.skip;  // siblings in orthant order
+                    j = c;
+                }
+                n_anc[k] = cnt;
+            }
+            const size_t ints = size_t(kMaxSplit + 1 + kMaxSplit + K * kMaxAnc);
+            HIP_TRY(h, hipMemcpyAsync(h->d_split, h->h_split, ints * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            const size_t need = size_t(K) * sh.seg_cap;
+            if (need > h->walk_planes_cap) {
+                if (h->d_walk_planes) (void)hipFree(h->d_walk_planes);
+                h->d_walk_planes = nullptr; h->walk_planes_cap = 0;
+                HIP_TRY(h, hipMalloc(&h->d_walk_planes, need * sizeof(float4)));
+                h->walk_planes_cap = need;
+            }
+            td.n_split = K;
+            td.split_first = h->d_split;
+            td.split_n_anc = h->d_split + kMaxSplit + 1;
+            td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
+            td.split_planes = h->d_walk_planes;
+            td.split_stride = size_t(sh.seg_cap);
+        } else {
+            if (!h->d_split) {
+                HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
+                HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
+            }
+            h->h_split[0] = 0; h->h_split[1] = int(h->tree.n_nodes); h->h_split[kMaxSplit + 1] = 0;
+            HIP_TRY(h, hipMemcpyAsync(h->d_split, h->h_split, (kMaxSplit + 2) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            td.n_split = 1;
+            td.split_first = h->d_split;
+            td.split_n_anc = h->d_split + kMaxSplit + 1;
+            td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
+        }
+    }
     {
         ForceTimer t(h);
         nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
@@ -403,9 +465,9 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_nodes, h->d_order, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes};
+                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters};
+    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

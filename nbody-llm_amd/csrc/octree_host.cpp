@@ -33,6 +33,11 @@
 namespace nbody {
 
 // ------------------------------------------------------------------------------- worker pool
+// Task ids are claimed from one monotonically growing counter; a run publishes [limit - n, limit)
+// and returns when `done` reaches n.  Workers need not all take part in a run (a sleeping worker
+// that wakes late simply finds nothing to claim), so a run costs no wake-up latency when the
+// workers are still spinning from the previous one -- a Barnes-Hut step calls run() a few dozen
+// times within ~1 ms -- and a late sleeper never delays the caller.
 WorkerPool::WorkerPool(int threads) {
     int extra = std::max(0, threads - 1);
     for (int i = 0; i < extra; ++i) workers_.emplace_back([this] { loop(); });
@@ -41,40 +46,41 @@ WorkerPool::WorkerPool(int threads) {
 WorkerPool::~WorkerPool() {
     {
         std::lock_guard<std::mutex> lk(m_);
-        stop_ = true;
-        stop_a_.store(true);
+        stop_.store(true);
     }
     cv_.notify_all();
     for (auto& t : workers_) t.join();
 }
 
-// Workers spin on the epoch counter for a while before they sleep on the condition variable: a
-// Barnes-Hut step calls run() five times within ~2 ms, and a futex wake-up per call per worker
-// (tens of microseconds each) would cost as much as the partition work itself.
-void WorkerPool::loop() {
-    uint64_t seen = 0;
+bool WorkerPool::try_one() {
+    long long t = next_.load(std::memory_order_acquire);
     for (;;) {
-        bool got = false;
-        for (int spin = 0; spin < 4000; ++spin) {  // ~0.1 ms
-            if (epoch_a_.load(std::memory_order_acquire) != seen || stop_a_.load(std::memory_order_relaxed)) { got = true; break; }
+        const long long lim = limit_.load(std::memory_order_acquire);
+        if (t >= lim) return false;
+        if (next_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) {
+            // the run that owns id t is still open (its caller waits for done_), so fn_/n_ are its own
+            const std::function<void(int)>* fn = fn_.load(std::memory_order_acquire);
+            (*fn)(int(t - (lim - n_.load(std::memory_order_acquire))));
+            done_.fetch_add(1, std::memory_order_acq_rel);
+            return true;
+        }
+    }
+}
+
+void WorkerPool::loop() {
+    for (;;) {
+        int idle = 0;
+        while (!stop_.load(std::memory_order_relaxed)) {
+            if (try_one()) { idle = 0; continue; }
+            if (++idle > 2000) break;  // ~50 us without work: go to sleep
             __builtin_ia32_pause();
         }
-        if (!got) {
-            std::unique_lock<std::mutex> lk(m_);
-            sleepers_++;
-            cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-            sleepers_--;
-        }
-        if (stop_a_.load(std::memory_order_relaxed)) return;
-        seen = epoch_a_.load(std::memory_order_acquire);
-        const std::function<void(int)>* fn = fn_;
-        const int n = n_tasks_;
-        for (;;) {
-            int t = next_.fetch_add(1, std::memory_order_relaxed);
-            if (t >= n) break;
-            (*fn)(t);
-        }
-        active_a_.fetch_sub(1, std::memory_order_acq_rel);
+        if (stop_.load(std::memory_order_relaxed)) return;
+        std::unique_lock<std::mutex> lk(m_);
+        sleepers_++;
+        cv_.wait(lk, [&] { return stop_.load() || next_.load() < limit_.load(); });
+        sleepers_--;
+        if (stop_.load()) return;
     }
 }
 
@@ -84,24 +90,18 @@ void WorkerPool::run(int n_tasks, const std::function<void(int)>& fn) {
         for (int t = 0; t < n_tasks; ++t) fn(t);
         return;
     }
+    done_.store(0, std::memory_order_relaxed);
+    fn_.store(&fn, std::memory_order_release);
+    n_.store(n_tasks, std::memory_order_release);
     bool wake;
     {
-        std::lock_guard<std::mutex> lk(m_);
-        fn_ = &fn;
-        n_tasks_ = n_tasks;
-        next_.store(0, std::memory_order_relaxed);
-        active_a_.store(int(workers_.size()), std::memory_order_relaxed);
-        ++epoch_;
-        epoch_a_.store(epoch_, std::memory_order_release);
+        std::lock_guard<std::mutex> lk(m_);  // pairs with the sleepers' predicate check
+        limit_.fetch_add(n_tasks, std::memory_order_acq_rel);
         wake = sleepers_ > 0;
     }
     if (wake) cv_.notify_all();
-    for (;;) {  // the caller works too
-        int t = next_.fetch_add(1, std::memory_order_relaxed);
-        if (t >= n_tasks) break;
-        fn(t);
-    }
-    while (active_a_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();  // every worker has left fn
+    while (try_one()) {}
+    while (done_.load(std::memory_order_acquire) != n_tasks) __builtin_ia32_pause();
 }
 
 // ------------------------------------------------------------------------------ output arrays
@@ -299,64 +299,97 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         fill(0, n);
         build_top(A, B, C, int(n), root, 0, top, tasks);
     } else {
-        // ---- level 0 in parallel: chunked classify + stable scatter; the root's sums are one
-        // sequential fold (their order is the reference's) running beside the chunk tasks
-        const int NC = T;
-        const size_t chunk = (n + NC - 1) / NC;
-        std::vector<std::array<int, 8>> cnt(NC);
-        NodeA root_node{0.f, 0.f, 0.f, 0.f};
-        pool.run(NC, [&](int t) {
-            const size_t k0 = std::min(n, size_t(t) * chunk), k1 = std::min(n, k0 + chunk);
-            fill(k0, k1);
-            std::array<int, 8> c{};
-            for (size_t k = k0; k < k1; ++k) {
-                const Item& it = A[k];
-                int o = (it.x > root.c[0] ? 1 : 0) | (it.y > root.c[1] ? 2 : 0) | (it.z > root.c[2] ? 4 : 0);
-                C[k] = uint8_t(o);
-                c[o]++;
-            }
-            cnt[t] = c;
-        });
-        int start[8], tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int t = 0; t < NC; ++t) for (int o = 0; o < 8; ++o) tot[o] += cnt[t][o];
-        { int run = 0; for (int o = 0; o < 8; ++o) { start[o] = run; run += tot[o]; } }
-        std::vector<std::array<int, 8>> off(NC);
-        { int run[8]; for (int o = 0; o < 8; ++o) run[o] = start[o];
-          for (int t = 0; t < NC; ++t) for (int o = 0; o < 8; ++o) { off[t][o] = run[o]; run[o] += cnt[t][o]; } }
-        pool.run(NC + 1, [&](int t) {
-            if (t == NC) {  // mass = sum m, com = sum(pos*m)/mass, folded left to right over all bodies
-                float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-                for (size_t k = 0; k < n; ++k) {
-                    const Item& it = A[k];
-                    mass += it.m; sx += it.x * it.m; sy += it.y * it.m; sz += it.z * it.m;
+        // ---- big nodes (more than `big` bodies) are partitioned level by level with every thread
+        // working on chunks of them; their folds (mass, com: sequential, the reference's order) run
+        // as separate tasks beside the chunk work.  Everything smaller becomes a subtree task.
+        // Depth alone is a poor cut: a Plummer sphere in a wide box keeps most bodies in 8 cells
+        // per level for several levels.
+        struct Big { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; int self; };
+        struct TNode { NodeA a{}; NodeB b{}; int child[8]; int task = -1; };
+        std::vector<TNode> tn;
+        auto new_tnode = [&](const Box& bx) { TNode t; t.b = NodeB{bx.w * bx.w, 0, bx.w, -1}; for (int& c : t.child) c = -1; tn.push_back(t); return int(tn.size()) - 1; };
+        const int big = std::max(2048, int(n / 64));
+        const int chunk = std::max(1024, big / 2);
+        pool.run(T, [&](int t) { const size_t c = (n + T - 1) / T; fill(std::min(n, size_t(t) * c), std::min(n, size_t(t + 1) * c)); });
+        std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root)}};
+        struct Piece { int node; int k0, k1; };
+        while (!level.empty()) {
+            std::vector<Piece> pieces;
+            for (int b = 0; b < int(level.size()); ++b)
+                for (int k0 = 0; k0 < level[b].n; k0 += chunk) pieces.push_back(Piece{b, k0, std::min(level[b].n, k0 + chunk)});
+            std::vector<std::array<int, 8>> pcnt(pieces.size());
+            const int NP = int(pieces.size()), NB = int(level.size());
+            pool.run(NP + NB, [&](int t) {
+                if (t >= NP) {  // the node's fold
+                    const Big& g = level[t - NP];
+                    float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+                    for (int k = 0; k < g.n; ++k) { const Item& it = g.src[k]; mass += it.m; sx += it.x * it.m; sy += it.y * it.m; sz += it.z * it.m; }
+                    tn[g.self].a = NodeA{sx / mass, sy / mass, sz / mass, mass};
+                    return;
                 }
-                root_node = NodeA{sx / mass, sy / mass, sz / mass, mass};
-                return;
+                const Piece& pc = pieces[t];
+                const Big& g = level[pc.node];
+                std::array<int, 8> c{};
+                for (int k = pc.k0; k < pc.k1; ++k) {
+                    const Item& it = g.src[k];
+                    int o = (it.x > g.box.c[0] ? 1 : 0) | (it.y > g.box.c[1] ? 2 : 0) | (it.z > g.box.c[2] ? 4 : 0);
+                    g.code[k] = uint8_t(o);
+                    c[o]++;
+                }
+                pcnt[t] = c;
+            });
+            // per node: orthant starts, then per piece: its write offsets (stable: pieces in order)
+            std::vector<std::array<int, 8>> nstart(NB), ntot(NB), poff(NP);
+            for (int b = 0; b < NB; ++b) ntot[b].fill(0);
+            for (int t = 0; t < NP; ++t) for (int o = 0; o < 8; ++o) ntot[pieces[t].node][o] += pcnt[t][o];
+            for (int b = 0; b < NB; ++b) { int run = 0; for (int o = 0; o < 8; ++o) { nstart[b][o] = run; run += ntot[b][o]; } }
+            { std::vector<std::array<int, 8>> run = nstart;
+              for (int t = 0; t < NP; ++t) for (int o = 0; o < 8; ++o) { poff[t][o] = run[pieces[t].node][o]; run[pieces[t].node][o] += pcnt[t][o]; } }
+            pool.run(NP, [&](int t) {
+                const Piece& pc = pieces[t];
+                const Big& g = level[pc.node];
+                int o8[8];
+                for (int o = 0; o < 8; ++o) o8[o] = poff[t][o];
+                for (int k = pc.k0; k < pc.k1; ++k) g.tmp[o8[g.code[k]]++] = g.src[k];
+            });
+            std::vector<Big> next;
+            for (int b = 0; b < NB; ++b) {
+                const Big g = level[b];
+                for (int o = 0; o < 8; ++o) {
+                    const int cn = ntot[b][o];
+                    if (!cn) continue;
+                    const Box cb = g.box.child(o);
+                    const int id = new_tnode(cb);
+                    tn[g.self].child[o] = id;
+                    Item* csrc = g.tmp + nstart[b][o];
+                    Item* ctmp = g.src + nstart[b][o];
+                    uint8_t* ccode = g.code + nstart[b][o];
+                    if (cn == 1) {
+                        tn[id].a = NodeA{csrc[0].x, csrc[0].y, csrc[0].z, csrc[0].m};
+                        tn[id].b.body = csrc[0].id;
+                    } else if (cn > big && g.depth + 1 < 24) {
+                        next.push_back(Big{csrc, ctmp, ccode, cn, cb, g.depth + 1, id});
+                    } else {
+                        tn[id].task = int(tasks.size());
+                        tasks.push_back(Task{csrc, ctmp, ccode, cn, cb, g.depth + 1, nullptr});
+                    }
+                }
             }
-            const size_t k0 = std::min(n, size_t(t) * chunk), k1 = std::min(n, k0 + chunk);
-            int o8[8];
-            for (int o = 0; o < 8; ++o) o8[o] = off[t][o];
-            for (size_t k = k0; k < k1; ++k) B[o8[C[k]]++] = A[k];
-        });
-        // ---- level 1: one task per non-empty orthant; each registers its depth-2 subtrees
-        std::vector<std::vector<TopEntry>> ctop(8);
-        std::vector<std::vector<Task>> ctasks(8);
-        pool.run(8, [&](int o) {
-            if (tot[o]) build_top(B + start[o], A + start[o], C + start[o], tot[o], root.child(o), 1, ctop[o], ctasks[o]);
-        });
-        top.emplace_back();
-        top[0].a = root_node;
-        top[0].b = NodeB{root.w * root.w, 0, root.w, -1};
-        for (int o = 0; o < 8; ++o) {
-            const int ebase = int(top.size()), tbase = int(tasks.size());
-            for (TopEntry e : ctop[o]) {
-                if (e.task >= 0) e.task += tbase;
-                e.end += ebase;
-                top.push_back(e);
-            }
-            for (Task& t : ctasks[o]) tasks.push_back(t);
+            level.swap(next);
         }
-        top[0].end = int(top.size());
+        // flatten the big-node tree in pre-order
+        std::vector<int> stack{0};
+        std::vector<int> open_end;  // entries whose `end` is patched when their subtree is complete
+        std::function<void(int)> emit = [&](int id) {
+            const int me = int(top.size());
+            top.emplace_back();
+            top[me].a = tn[id].a;
+            top[me].b = tn[id].b;
+            top[me].task = tn[id].task;
+            for (int o = 0; o < 8; ++o) if (tn[id].child[o] >= 0) emit(tn[id].child[o]);
+            top[me].end = int(top.size());
+        };
+        emit(0);
     }
 
     lap("top");

@@ -24,18 +24,17 @@ public:
 
 private:
     void loop();
+    bool try_one();
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_;
-    const std::function<void(int)>* fn_ = nullptr;
-    std::atomic<int> next_{0};
-    std::atomic<int> active_a_{0};
-    std::atomic<uint64_t> epoch_a_{0};
-    std::atomic<bool> stop_a_{false};
-    int n_tasks_ = 0;
-    int sleepers_ = 0;
-    uint64_t epoch_ = 0;
-    bool stop_ = false;
+    std::atomic<const std::function<void(int)>*> fn_{nullptr};
+    std::atomic<long long> next_{0};    // next task id to claim (grows over the pool's lifetime)
+    std::atomic<long long> limit_{0};   // ids below this are published
+    std::atomic<int> n_{0};             // size of the open run
+    std::atomic<int> done_{0};          // tasks of the open run that have finished
+    std::atomic<bool> stop_{false};
+    int sleepers_ = 0;                  // under m_
 };
 
 struct NodeA { float x, y, z, m; };               // centre of mass, mass

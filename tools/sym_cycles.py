@@ -15,11 +15,15 @@ sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FA
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
 for w, dv in [(w, d) for w in wps_list for d in dbg_list]:
     wps.value, dbg.value = w, dv
-    for _ in range(200):   # ~0.2 s of back-to-back launches so the clock settles
-        sim.update_forces()
+    mode = os.environ.get('SYM_CYCLES_MODE', 'forces')
+    if mode == 'steps':
+        sim.steps(200)
+    else:
+        for _ in range(200):   # ~0.2 s of back-to-back launches so the clock settles
+            sim.update_forces()
     sim.sync()
     A = (n + 511) // 512
-    K = min(96, (6144 if w >= 6 else 4096) // A)
+    K = min(126, 3072 // A)
     nw = min(8192, A * K)
     buf = (ctypes.c_ulonglong * (3 * nw))()
     assert nb.lib.nbody_sym_read_stamps(buf, nw) == 0

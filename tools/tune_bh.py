@@ -6,17 +6,18 @@ nb = graft.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ics = nb.plummer(n)
 var = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_variant")
+split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
 for math in (nb.STRICT, nb.FAST):
     sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BARNES_HUT, math_mode=math)
     sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.25)
-    for v in (0, 1):
-        var.value = v
+    for v, k in ((0, 1), (0, 4), (0, 8), (0, 16), (0, 32), (1, 1), (1, 8), (1, 16), (1, 32)):
+        var.value = v; split.value = k
         sim.steps(3); sim.sync()
         sim.set_profiling(True); sim.reset_stats()
         t0 = time.perf_counter()
         sim.steps(20); sim.sync()
         dt = (time.perf_counter() - t0) / 20
         s = sim.stats()
-        print(f"math {'fast' if math else 'strict'} walk variant {v}: step {dt*1e3:.3f} ms; walk kernel {s.force_kernel_ms/s.force_launches:.3f} ms; "
+        print(f"math {'fast' if math else 'strict'} walk variant {v} split {k}: step {dt*1e3:.3f} ms; walk kernel {s.force_kernel_ms/s.force_launches:.3f} ms; "
               f"build {s.tree_build_ms/20:.3f} ms; copy+wait {s.tree_copy_ms/20:.3f} ms; visits/step {s.node_visits/20:.3e}; accepted/step {s.interactions/20:.3e}")
     sim.close()
