@@ -340,10 +340,15 @@ __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict_
                                                        float4* __restrict__ acc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= *count) return;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    // compensated (Kahan) sum over the planes, fixed order: the kernel is bandwidth-bound, the extra
+    // flops are free, and with ~1000 planes at N = 2^20 a plain f32 sum would dominate the error
+    float sx = 0.f, sy = 0.f, sz = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
     for (int p = 0; p < n_planes; ++p) {
         const float4 v = planes[size_t(p) * plane_stride + i];
-        sx += v.x; sy += v.y; sz += v.z;
+        const float yx = v.x - cx, yy = v.y - cy, yz = v.z - cz;
+        const float tx = sx + yx, ty = sy + yy, tz = sz + yz;
+        cx = (tx - sx) - yx; cy = (ty - sy) - yy; cz = (tz - sz) - yz;
+        sx = tx; sy = ty; sz = tz;
     }
     acc[i] = make_float4(g * sx, g * sy, g * sz, 0.f);
 }

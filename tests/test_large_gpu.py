@@ -1,0 +1,57 @@
+"""BASELINE configs[3]/[4] body counts on ONE GPU (the 8-GPU runs themselves belong to the driver):
+the same kernels at N = 2^20 through size-independent properties and sampled rows of the oracle."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BOX = ((0.0, 0.0, 0.0), 64.0)
+
+
+def test_brute_force_one_million_bodies_sampled_rows_and_momentum(gpu, orc):
+    """configs[3]'s 1 048 576 bodies: 2048 resident sets, 1023 set distances (2 GiB of partial-sum
+    planes).  Rows of the f32 oracle over all partners for a sample of bodies; total momentum of the
+    force field ~ 0."""
+    nb = gpu
+    n = 1 << 20
+    sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
+    ics = nb.plummer(n, seed=7)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        got = sim.get_points()["acceleration"]
+    assert np.isfinite(got).all()
+    ref = ics.copy().astype(orc.P32)
+    ref64 = orc.to_f64(ics)
+    sd64 = dict(sd, g_soft=float(np.float32(sd["g_soft"])))
+    for lo, hi in [(0, 48), (524288 - 24, 524288 + 24), (n - 48, n)]:
+        orc.bf_update_forces_range(ref, sd, lo, hi, threads=16)
+        orc.bf_update_forces_range(ref64, sd64, lo, hi, threads=16)
+        exact = ref64["acceleration"][lo:hi]
+        # a million-term f32 sequential sum (the reference's order) carries ~1e-4 of rounding itself:
+        # the kernel's partial sums must be within 2e-5 of the f64 result and no worse than the reference
+        e_fast, e_ref = rel_err(got[lo:hi], exact), rel_err(ref["acceleration"][lo:hi], exact)
+        assert e_fast < 2e-5 and e_fast <= max(e_ref, 2e-6), (e_fast, e_ref)
+        assert rel_err(got[lo:hi], ref["acceleration"][lo:hi]) < 2e-4
+    m = ics["mass"].astype(np.float64)[:, None]
+    p = (got.astype(np.float64) * m).sum(0)
+    assert np.abs(p).max() < 1e-6 * np.abs(got.astype(np.float64) * m).sum()
+
+
+def test_barnes_hut_one_million_bodies_counts_and_accelerations(gpu, orc):
+    """1 048 576 bodies, theta = 0.5: node counts equal the threaded oracle's, accelerations to
+    rounding (the oracle's recursive build + walk takes a few seconds on 16 threads)."""
+    nb = gpu
+    n = 1 << 20
+    sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(n, seed=8)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=16)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
