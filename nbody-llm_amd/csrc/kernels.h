@@ -62,7 +62,7 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
                         int n_upper, float g_soft2);
 void launch_bf_os(hipStream_t s, const Shard& sh, int A, int K, float4* planes, size_t plane_stride, float g_soft2);
 void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4* planes, int n_upper, float g,
-                        float g_soft2);
+                        float g_soft2, const float* kick_dt);
 
 // K5: BarnesHutSimulation::calc_force (barnes_hut.rs:185-203) over a linearised octree
 struct TreeDev {

@@ -114,6 +114,14 @@ __device__ __forceinline__ void pair_evals(const float (&xi)[IPT], const float (
 
 }  // namespace
 
+template <int IPT>
+__device__ __forceinline__ void sym_rest_wave(const float4* __restrict__ pos, int n, int A, int group, int slice,
+                                              int n_slices, float& ax, float& ay, float& az, float eps2);
+
+template <int IPT, int NW>
+__device__ __forceinline__ void sym_rest_block(const float4* __restrict__ pos, int n, int A, int group,
+                                               float4* __restrict__ plane, float eps2, float (*red)[3][64]);
+
 // WPB waves per workgroup, sized so that exactly one (WPB = 16) or two (WPB = 12) workgroups fit a
 // CU: the dispatcher then has no choice but to spread the grid evenly.  With small workgroups it
 // packs some CUs to their register limit and leaves others nearly empty, and the kernel lasts as
@@ -128,6 +136,14 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
     // SIMD gets WPB/4 CONSECUTIVE slices -- one short one and the long ones -- and all four SIMDs of
     // the CU carry the same number of chunks.
     const int wslot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_main_blocks = (A * K + WPB - 1) / WPB;
+    if (int(blockIdx.x) >= n_main_blocks) {
+        // tail filler: the workgroups after the rotation workgroups are dispatched as CUs fall free
+        // and do the own-set / opposite-set pairs (64 bodies per workgroup) inside the same launch
+        __shared__ float red[WPB - 1][3][64];
+        sym_rest_block<IPT, WPB>(pos, *count, A, blockIdx.x - n_main_blocks, planes + size_t(sym_sets + K) * plane_stride, eps2, red);
+        return;
+    }
     const int gw = blockIdx.x * WPB + (wslot & 3) * (WPB / 4) + (wslot >> 2);  // global slice index
     if (gw >= A * K) return;
     const int a = gw / K;                        // resident set
@@ -295,27 +311,26 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_os(const float4* __restrict__ p
 // when A is even, against the opposite set -- one-sided, since the opposite set does the same for
 // ours.  64 bodies per workgroup, the 1 or 2 windows of 64*IPT partners split over 8 waves whose
 // partner index is wave-uniform (scalar loads); ~3 % of the pair evaluations.
+// One wave's share of those pairs: 64 bodies (one per lane) against slice `slice` of `n_slices` of
+// each of the 1 or 2 windows; the caller adds the slices up.
 template <int IPT>
-__global__ __launch_bounds__(512) void k_bf_sym_rest(const float4* __restrict__ pos, const int* __restrict__ count,
-                                                     int A, float4* __restrict__ plane, float eps2) {
-    constexpr int SET = 64 * IPT, WAVES = 8, SLICE = SET / WAVES;
-    __shared__ float red[WAVES - 1][3][64];
+__device__ __forceinline__ void sym_rest_wave(const float4* __restrict__ pos, int n, int A, int group, int slice,
+                                              int n_slices, float& ax, float& ay, float& az, float eps2) {
+    constexpr int SET = 64 * IPT;
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = *count;
-    const int i = blockIdx.x * 64 + lane;
-    const int a = (blockIdx.x * 64) / SET;
+    const int i = group * 64 + lane;
+    const int a = (group * 64) / SET;
     const float4 pi = (i < n) ? pos[i] : make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
-    float ax = 0.f, ay = 0.f, az = 0.f;
+    ax = ay = az = 0.f;
     const int n_win = (A % 2 == 0 && A > 1) ? 2 : 1;
     for (int w = 0; w < n_win; ++w) {
         int set = (w == 0) ? a : a + A / 2;
         if (set >= A) set -= A;
-        const int j0 = set * SET + wv * SLICE;
-        const int j1 = min(n, j0 + SLICE);
+        const int j0 = set * SET + SET * slice / n_slices;
+        const int j1 = min(n, set * SET + SET * (slice + 1) / n_slices);
 #pragma unroll 8
         for (int j = j0; j < j1; ++j) {
-            const float4 pj = pos[j];  // wave-uniform address
+            const float4 pj = pos[j];  // wave-uniform address: scalar loads
             const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
             const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, eps2)));
             const float rinv = __builtin_amdgcn_rsqf(r2);
@@ -326,18 +341,40 @@ __global__ __launch_bounds__(512) void k_bf_sym_rest(const float4* __restrict__ 
             az = __builtin_fmaf(dz, sj, az);
         }
     }
+}
+
+// a workgroup of NW waves: 64 bodies, the windows cut into NW slices, slices added in wave order
+template <int IPT, int NW>
+__device__ __forceinline__ void sym_rest_block(const float4* __restrict__ pos, int n, int A, int group,
+                                               float4* __restrict__ plane, float eps2, float (*red)[3][64]) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float ax, ay, az;
+    sym_rest_wave<IPT>(pos, n, A, group, wv, NW, ax, ay, az, eps2);
     if (wv > 0) { red[wv - 1][0][lane] = ax; red[wv - 1][1][lane] = ay; red[wv - 1][2][lane] = az; }
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
-        for (int w = 0; w < WAVES - 1; ++w) { ax += red[w][0][lane]; ay += red[w][1][lane]; az += red[w][2][lane]; }
-        plane[i] = make_float4(ax, ay, az, 0.f);
+        for (int w = 0; w < NW - 1; ++w) { ax += red[w][0][lane]; ay += red[w][1][lane]; az += red[w][2][lane]; }
+        plane[group * 64 + lane] = make_float4(ax, ay, az, 0.f);
     }
 }
 
+// stand-alone launch of the above (used when there is no rotation kernel to ride on)
+template <int IPT>
+__global__ __launch_bounds__(512) void k_bf_sym_rest(const float4* __restrict__ pos, const int* __restrict__ count,
+                                                     int A, float4* __restrict__ plane, float eps2) {
+    __shared__ float red[7][3][64];
+    sym_rest_block<IPT, 8>(pos, *count, A, blockIdx.x, plane, eps2, red);
+}
+
+// the fixed-order sum of the planes; optionally followed at once by integrate_after_force
+// (shared.rs:141-148: v += a*dt; x += (v*0.5)*dt) so that a step needs no separate K3 launch
+template <bool KICK>
 __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict__ planes, int n_planes,
                                                        size_t plane_stride, const int* __restrict__ count, float g,
-                                                       float4* __restrict__ acc) {
+                                                       float4* __restrict__ acc, float4* __restrict__ pos,
+                                                       float4* __restrict__ vel, float dt) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= *count) return;
     // compensated (Kahan) sum over the planes, fixed order: the kernel is bandwidth-bound, the extra
@@ -350,7 +387,15 @@ __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict_
         cx = (tx - sx) - yx; cy = (ty - sy) - yy; cz = (tz - sz) - yz;
         sx = tx; sy = ty; sz = tz;
     }
-    acc[i] = make_float4(g * sx, g * sy, g * sz, 0.f);
+    const float4 a = make_float4(g * sx, g * sy, g * sz, 0.f);
+    acc[i] = a;
+    if (KICK) {
+        float4 p = pos[i], v = vel[i];
+        v.x += a.x * dt; v.y += a.y * dt; v.z += a.z * dt;
+        p.x += (v.x * 0.5f) * dt; p.y += (v.y * 0.5f) * dt; p.z += (v.z * 0.5f) * dt;
+        vel[i] = v;
+        pos[i] = p;
+    }
 }
 
 }  // namespace nbody
@@ -375,9 +420,21 @@ SymPlan make_sym_plan(int n_upper) {
     // trims the tail at the price of more resident-side planes
     p.wpb = nbody_sym_wpb == 8 ? 8 : nbody_sym_wpb == 12 ? 12 : 16;
     const int resident_wgs_per_cu = (p.wpb == 8) ? 2 : 1;
-    const int slots = 256 * resident_wgs_per_cu * p.wpb * std::max(1, nbody_sym_rounds);
-    int K = slots / p.A;
-    if (K > 126) K = 126;
+    const int slots = 256 * resident_wgs_per_cu * p.wpb;  // waves the chip holds at once
+    // A * K waves run in ceil(A*K/slots) rounds; pick the K (few, long slices preferred) whose last
+    // round is fullest -- e.g. A = 2048 sets: K = 1 would fill 2/3 of one round, K = 3 fills two
+    int K = 1;
+    double best = 0.0;
+    const int k_hi = std::min(126, std::min(L, std::max(1, slots * std::max(1, nbody_sym_rounds) * 4 / p.A)));
+    for (int k = 1; k <= k_hi; ++k) {
+        const long long waves = (long long)p.A * k;
+        const long long rounds = (waves + slots - 1) / slots;
+        if (rounds > 4 * std::max(1, nbody_sym_rounds) && k > 1) break;
+        const double fill = double(waves) / double(rounds * slots);
+        const double even = (L % k == 0) ? 1.0 : double(L / k) / double(L / k + 1);  // shortest/longest slice
+        const double per_wave = double(L) / k / (double(L) / k + 0.3);  // set-up cost of a wave ~ 0.3 chunk
+        if (fill * even * per_wave > best + 1e-9) { best = fill * even * per_wave; K = k; }
+    }
     if (K > L) K = L;
     if (K < 1) K = 1;
     p.K = K;
@@ -405,7 +462,9 @@ uint64_t sym_main_pairs(const SymPlan& p, size_t n) {
 void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
                         int n_upper, float g_soft2) {
     if (n_upper <= 0 || p.sym_sets <= 0) return;
-    const dim3 grid((p.A * p.K + p.wpb - 1) / p.wpb), block(p.wpb * 64);
+    const int main_blocks = (p.A * p.K + p.wpb - 1) / p.wpb;
+    const int rest_blocks = int(p.n_pad / 64);  // one workgroup per 64 bodies
+    const dim3 grid(main_blocks + rest_blocks), block(p.wpb * 64);
 #define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.n_pad, g_soft2)
     if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
         if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
@@ -426,17 +485,24 @@ void launch_bf_os(hipStream_t s, const Shard& sh, int A, int K, float4* planes, 
                        sh.n_seg, sh.seg_cap, sh.my_seg, A, K, planes, plane_stride, g_soft2);
 }
 
-// own/opposite-set pairs + the fixed-order sum of the planes into acc
+// the fixed-order sum of the planes into acc (the own/opposite-set pairs ride on the rotation
+// kernel's launch; without one they get their own).  kick_dt != nullptr fuses integrate_after_force.
 void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4* planes, int n_upper, float g,
-                        float g_soft2) {
+                        float g_soft2, const float* kick_dt) {
     if (n_upper <= 0) return;
-    float4* resident0 = planes + size_t(p.sym_sets) * p.n_pad;
-    if (p.sym_sets == 0)  // no symmetric pass: the resident-side planes are never written
+    if (p.sym_sets == 0) {  // no rotation pass: the resident-side planes are never written
+        float4* resident0 = planes + size_t(p.sym_sets) * p.n_pad;
         (void)hipMemsetAsync(resident0, 0, size_t(p.K) * p.n_pad * sizeof(float4), s);
-    hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(), sh.own_count(), p.A,
-                       planes + size_t(p.sym_sets + p.K) * p.n_pad, g_soft2);
-    hipLaunchKernelGGL(k_bf_sym_reduce, dim3((n_upper + 255) / 256), dim3(256), 0, s, planes, p.n_planes, p.n_pad,
-                       sh.own_count(), g, sh.acc);
+        hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(),
+                           sh.own_count(), p.A, planes + size_t(p.sym_sets + p.K) * p.n_pad, g_soft2);
+    }
+    const dim3 grid((n_upper + 255) / 256);
+    if (kick_dt)
+        hipLaunchKernelGGL(k_bf_sym_reduce<true>, grid, dim3(256), 0, s, planes, p.n_planes, p.n_pad, sh.own_count(), g,
+                           sh.acc, sh.own_pos(), sh.vel, *kick_dt);
+    else
+        hipLaunchKernelGGL(k_bf_sym_reduce<false>, grid, dim3(256), 0, s, planes, p.n_planes, p.n_pad, sh.own_count(), g,
+                           sh.acc, sh.own_pos(), sh.vel, 0.f);
 }
 
 }  // namespace nbody

@@ -75,6 +75,8 @@ struct NbodyHandle {
     float4* d_planes = nullptr;
     size_t planes_cap = 0;  // float4 entries
     int sym_waves = 0;
+    bool kick_pending = false;  // step_end asks the force pass to fuse integrate_after_force if it can
+    float kick_dt = 0.f;
     uint64_t sym_pairs = 0;   // unordered pairs the rotation kernel covers at the current n_local
     size_t sym_pairs_n = 0;
 
@@ -273,7 +275,8 @@ int bf_forces(NbodyHandle* h) {
             nbody::launch_bf_sym_main(h->stream, h->sh, p, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
         }
         timed = 2 * h->sym_pairs;
-        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2);
+        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2, h->kick_pending ? &h->kick_dt : nullptr);
+        h->kick_pending = false;
     } else {
         // own shard symmetric, the other shards one-sided, one fixed-order sum over all the planes
         nbody::launch_bf_sym_main(h->stream, h->sh, p, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
@@ -282,7 +285,8 @@ int bf_forces(NbodyHandle* h) {
             nbody::launch_bf_os(h->stream, h->sh, p.A, p.k_os, h->d_planes + size_t(p.n_planes - p.k_os) * p.n_pad, p.n_pad, eps2);
         }
         timed = uint64_t(h->n_local) * uint64_t(tot - h->n_local);
-        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2);
+        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2, h->kick_pending ? &h->kick_dt : nullptr);
+        h->kick_pending = false;
     }
     HIP_TRY(h, hipGetLastError());
     if (tot > 0) {
@@ -365,7 +369,7 @@ int bh_forces(NbodyHandle* h) {
         constexpr int kMaxSplit = 32, kMaxAnc = 192;
         int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((8192 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
         K = std::max(1, std::min(kMaxSplit, K));
-        if (size_t(K) * 64 > h->tree.n_nodes) K = 1;
+        while (K > 1 && size_t(K) * 16 > h->tree.n_nodes) K /= 2;
         if (K > 1) {
             if (!h->d_split) {
                 HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
@@ -439,9 +443,12 @@ int step_begin(NbodyHandle* h, float dt) {
 }
 
 int step_end(NbodyHandle* h, float dt) {
+    h->kick_pending = true;   // a force pass that ends in a reduction kernel applies the kick itself
+    h->kick_dt = dt;
     int rc = forces(h);                                                        // update_forces
-    if (rc) return rc;
-    nbody::launch_kick_drift(h->stream, h->sh, int(h->n_local), dt);           // integrate_after_force
+    if (rc) { h->kick_pending = false; return rc; }
+    if (h->kick_pending) nbody::launch_kick_drift(h->stream, h->sh, int(h->n_local), dt);  // integrate_after_force
+    h->kick_pending = false;
     HIP_TRY(h, hipGetLastError());
     h->elapsed += dt;                                                          // elapsed += dt
     h->stats.steps += 1;
