@@ -124,10 +124,19 @@ def main():
     sim = nb.Simulation(ics, *box, method=method, math_mode=math_mode, capacity=n, device=local_rank,
                         rank=rank, world_size=world)
     sim.settings = nb.Settings(**st)
-    if dist is not None:
-        ident = [nb.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        sim.comm_init(ident[0])
+    if dist is not None and (world > 1 or os.environ.get("NBODY_BENCH_FORCE_COMM")):
+        # RCCL prints a version banner on stdout at init: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            ident = [nb.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            sim.comm_init(ident[0])
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     sim.init()
 
     def barrier():

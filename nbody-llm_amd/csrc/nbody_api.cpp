@@ -90,6 +90,9 @@ struct NbodyHandle {
     // multi-GPU
     ncclComm_t comm = nullptr;
     bool comm_ready = false;
+    hipStream_t comm_stream = nullptr;   // the exchange runs here, beside the own-shard force kernel
+    hipEvent_t ev_drifted = nullptr, ev_gathered = nullptr;
+    bool exchange_in_flight = false;
 
     std::string err;
 };
@@ -177,13 +180,26 @@ size_t total_upper(const NbodyHandle* h) {
 
 // the once-per-step exchange of half-drifted positions: an in-place
 // all-gather of the own segment into every rank's pos_all, plus the live counts
-int exchange(NbodyHandle* h) {
+int exchange_begin(NbodyHandle* h) {
     if (h->sh.n_seg == 1 && !h->comm_ready) return NBODY_OK;  // (a 1-rank communicator still runs the collective)
     if (!h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    // comm stream: after the drift/compaction of this step, beside whatever the compute stream does next
+    HIP_TRY(h, hipEventRecord(h->ev_drifted, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_drifted, 0));
     NCCL_TRY(h, ncclGroupStart());
-    NCCL_TRY(h, ncclAllGather(h->sh.own_pos(), h->sh.pos_all, size_t(h->sh.seg_cap) * 4, ncclFloat, h->comm, h->stream));
-    NCCL_TRY(h, ncclAllGather(h->sh.own_count(), h->sh.seg_count, 1, ncclInt32, h->comm, h->stream));
+    NCCL_TRY(h, ncclAllGather(h->sh.own_pos(), h->sh.pos_all, size_t(h->sh.seg_cap) * 4, ncclFloat, h->comm, h->comm_stream));
+    NCCL_TRY(h, ncclAllGather(h->sh.own_count(), h->sh.seg_count, 1, ncclInt32, h->comm, h->comm_stream));
     NCCL_TRY(h, ncclGroupEnd());
+    HIP_TRY(h, hipEventRecord(h->ev_gathered, h->comm_stream));
+    h->exchange_in_flight = true;
+    return NBODY_OK;
+}
+
+// everything enqueued on the compute stream after this call sees the gathered positions
+int exchange_wait(NbodyHandle* h) {
+    if (!h->exchange_in_flight) return NBODY_OK;
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_gathered, 0));
+    h->exchange_in_flight = false;
     return NBODY_OK;
 }
 
@@ -264,6 +280,10 @@ int bf_forces(NbodyHandle* h) {
     }
     const nbody::SymPlan& p = h->sym_plan;
     uint64_t timed = 0;  // interactions of the launch the HIP events bracket (the dominant one)
+    if (!(sym && sharded)) {
+        int rc = exchange_wait(h);
+        if (rc) return rc;
+    }
     if (!sym) {
         ForceTimer t(h);
         if (h->cfg.math_mode == NBODY_MATH_STRICT) nbody::launch_bf_forces_strict(h->stream, h->sh, int(h->n_local), h->g, eps2);
@@ -278,8 +298,13 @@ int bf_forces(NbodyHandle* h) {
         nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2, h->kick_pending ? &h->kick_dt : nullptr);
         h->kick_pending = false;
     } else {
-        // own shard symmetric, the other shards one-sided, one fixed-order sum over all the planes
+        // own shard symmetric (needs no remote data: it overlaps the exchange), the other shards
+        // one-sided, one fixed-order sum over all the planes
         nbody::launch_bf_sym_main(h->stream, h->sh, p, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
+        {
+            int rc = exchange_wait(h);
+            if (rc) return rc;
+        }
         {
             ForceTimer t(h);
             nbody::launch_bf_os(h->stream, h->sh, p.A, p.k_os, h->d_planes + size_t(p.n_planes - p.k_os) * p.n_pad, p.n_pad, eps2);
@@ -318,6 +343,10 @@ int ensure_tree_dev(NbodyHandle* h, size_t nodes, size_t order) {
 // positions, then one walk per body.
 int bh_forces(NbodyHandle* h) {
     Shard& sh = h->sh;
+    {
+        int rc = exchange_wait(h);
+        if (rc) return rc;
+    }
     auto t0 = clk::now();
     // positions of every segment (upper-bound counts) + the live counts, one sync
     for (int s = 0; s < sh.n_seg; ++s) {
@@ -458,7 +487,7 @@ int step_end(NbodyHandle* h, float dt) {
 int step_impl(NbodyHandle* h, float dt) {
     int rc = step_begin(h, dt);
     if (rc) return rc;
-    rc = exchange(h);
+    rc = exchange_begin(h);   // the force pass waits for it where it first needs remote bodies
     if (rc) return rc;
     return step_end(h, dt);
 }
@@ -467,7 +496,11 @@ void free_all(NbodyHandle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->ev_drifted) (void)hipEventDestroy(h->ev_drifted);
+    if (h->ev_gathered) (void)hipEventDestroy(h->ev_gathered);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (auto& ev : h->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
@@ -770,7 +803,7 @@ int nbody_update_forces(NbodyHandle* h) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->cfg.method == NBODY_BARNES_HUT && !h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
-    rc = exchange(h);
+    rc = exchange_begin(h);
     if (rc) return rc;
     return forces(h);
 }
@@ -891,6 +924,11 @@ int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
     NCCL_TRY(h, ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+    if (!h->comm_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_drifted, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_gathered, hipEventDisableTiming));
+    }
     h->comm_ready = true;
     return NBODY_OK;
 }

@@ -155,6 +155,25 @@ def test_rccl_single_rank_communicator(gpu, orc):
         assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
 
 
+@pytest.mark.parametrize("method,math", [("BRUTE_FORCE", "FAST"), ("BARNES_HUT", "STRICT")])
+def test_rccl_single_rank_communicator_other_paths(gpu, orc, method, math):
+    """Same with the fast symmetric path (n >= 8192: the exchange runs on its own stream beside the
+    force kernel) and with Barnes-Hut."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(9000, seed=4)
+    outs = []
+    for with_comm in (False, True):
+        with nb.Simulation(ics, *BOX, method=getattr(nb, method), math_mode=getattr(nb, math)) as sim:
+            sim.settings = nb.Settings(**sd)
+            if with_comm:
+                sim.comm_init(nb.comm_unique_id())
+            sim.steps(3)
+            sim.update_forces()
+            outs.append(sim.get_points())
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_sharded_handle_without_communicator_fails_loudly(gpu):
     nb = gpu
     ics = nb.plummer(64)
