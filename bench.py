@@ -101,7 +101,13 @@ def main():
         args.gpus = world
 
     dist = None
+    json_fd = None
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:  # launched by torch.distributed.run (any N)
+        # gloo and RCCL print connection/version banners on stdout: stdout is pointed at stderr for
+        # the whole run and the one JSON line goes to the original descriptor at the end
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         # torch bundles its own ROCm runtime libraries under the same SONAMEs as /opt/rocm's; a
         # process must end up with ONE set, so torch goes first and libnbody_hip.so binds to what is
         # already loaded (the other order aborts at exit with a double free).  N = 1 never imports torch.
@@ -125,18 +131,9 @@ def main():
                         rank=rank, world_size=world)
     sim.settings = nb.Settings(**st)
     if dist is not None and (world > 1 or os.environ.get("NBODY_BENCH_FORCE_COMM")):
-        # RCCL prints a version banner on stdout at init: keep stdout for the one JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            ident = [nb.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ident, src=0)
-            sim.comm_init(ident[0])
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        ident = [nb.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        sim.comm_init(ident[0])
     sim.init()
 
     def barrier():
@@ -235,12 +232,16 @@ def main():
     sim.close()
 
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             orc = graft.load_oracle()
             result["cpu_baseline"] = cpu_baseline(orc, ics, st, box, args.workload)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result)
+        if json_fd is not None:
+            os.write(json_fd, (line + "\n").encode())
+        else:
+            print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
