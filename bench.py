@@ -38,8 +38,8 @@ BH_BYTES_PER_VISIT = 32      # K5: one 32-byte node record per opening test
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["bf", "bh"], default="bf",
                     help="bf = configs[1] (65 536-body brute force, the metric's config); bh = configs[2]")
     ap.add_argument("--n", type=int, default=65536, help="bodies over all GPUs")

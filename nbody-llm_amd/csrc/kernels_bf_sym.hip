@@ -401,7 +401,6 @@ __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict_
 }  // namespace nbody
 namespace nbody { int read_sym_stamps(unsigned long long* out, int n_waves); }
 extern "C" int nbody_sym_read_stamps(unsigned long long* out, int n_waves) { return nbody::read_sym_stamps(out, n_waves); }
-extern "C" int nbody_sym_waves_per_simd = 4;  // (unused; older tuning scripts set it)
 extern "C" int nbody_sym_wpb = 12;     // waves per workgroup: 16, 12 or 8   (tuning hooks, tools/tune_sym.py)
 extern "C" int nbody_sym_rounds = 1;   // rounds of workgroups per CU
 extern "C" int nbody_sym_debug = 0;    // 4: diagnostic build with in-kernel cycle stamps

@@ -120,8 +120,6 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
 // changes.  With one wave per SIMD (N = 65 536 is only 1 024 waves) the dependent scalar-load chain is
 // exposed, so this form is slower than k_bh_walk today (1.26 vs 0.83 ms); it needs the node range
 // split over several waves per body group to pay off (Barnes-Hut, next steps).
-__device__ int nbody_bh_load_mode_dev;
-#define nbody_bh_load_mode LOADMODE
 template <bool FAST, int LOADMODE>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __restrict__ nodes, int n_nodes,
                                                              const int* __restrict__ order, int n_order,
@@ -146,7 +144,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
         // uniform address: ONE 32-byte scalar load (left to itself the compiler fetches the mass in a
         // third, dependent s_load under the accept branch)
         float4 A, B;
-        if (nbody_bh_load_mode == 0) {
+        if (LOADMODE == 0) {
             f32x8 rec;
             asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(nodes + i) : "memory");
             A = make_float4(rec[0], rec[1], rec[2], rec[3]);

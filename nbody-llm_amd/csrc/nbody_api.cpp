@@ -23,7 +23,6 @@
 #include <vector>
 
 extern "C" int nbody_bf_fast_variant;
-extern "C" int nbody_sym_waves_per_simd;
 extern "C" int nbody_sym_wpb;
 extern "C" int nbody_sym_rounds;
 extern "C" int nbody_bh_walk_split;
@@ -579,7 +578,6 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_SYM_WAVES")) nbody_sym_waves_per_simd = std::max(1, std::min(8, std::atoi(v)));
     *out = h;
     return NBODY_OK;
 }

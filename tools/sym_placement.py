@@ -6,15 +6,15 @@ import __graft_entry__ as graft
 nb = graft.load_package()
 n = 65536
 ics = nb.plummer(n)
-wps = ctypes.c_int.in_dll(nb.lib, "nbody_sym_waves_per_simd")
+wps = ctypes.c_int.in_dll(nb.lib, "nbody_sym_wpb")   # waves per workgroup (16, 12 or 8)
 dbg = ctypes.c_int.in_dll(nb.lib, "nbody_sym_debug")
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST)
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
-wps.value, dbg.value = 4, 4
+wps.value, dbg.value = 12, 4
 for _ in range(50):
     sim.update_forces()
 sim.sync()
-nw = 4096
+nw = 3072
 buf = (ctypes.c_ulonglong * (3 * nw))()
 assert nb.lib.nbody_sym_read_stamps(buf, nw) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 3)

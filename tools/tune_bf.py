@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
 nb = graft.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [4, 2, 1, 8, 42, 24, 116]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4]
 ics = nb.plummer(n)
 var = ctypes.c_int.in_dll(nb.lib, "nbody_bf_fast_variant")
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST)
