@@ -178,8 +178,10 @@ def main():
         bodies_per_launch = n / world
         if args.workload == "bf":
             alg_bytes = BF_BYTES_PER_BODY * bodies_per_launch
+            cross = os.environ.get("NBODY_CROSS_SYM", "1") != "0"
             kernel = ("k_bf_strict" if args.math == "strict" else
-                      "k_bf_sym" if (world == 1 and n >= 8192) else "k_bf_fast")
+                      "k_bf_sym" if (world == 1 and n >= 8192) else
+                      ("k_bf_cross" if cross else "k_bf_os") if (world > 1 and n // world >= 2048) else "k_bf_fast")
             # interactions the timed (dominant) launches evaluated; k_bf_sym leaves ~2 % (own and
             # opposite resident set) to the small companion kernel k_bf_sym_rest
             flops_per_launch = FLOP_PER_INTERACTION * k_inter / max(1.0, launches)
@@ -220,7 +222,9 @@ def main():
                 "n_bodies": n, "method": "brute_force" if args.workload == "bf" else "barnes_hut",
                 "math": args.math, "ics": f"plummer seed={args.seed}", "dt": st["dt"], "g_soft": st["g_soft"],
                 "theta2": theta2 if args.workload == "bh" else None, "box_width": box[1],
-                "parallelism": "1 GPU" if world == 1 else f"{world} index-block shards, RCCL all-gather of positions per step",
+                "parallelism": "1 GPU" if world == 1 else
+                               f"{world} index-block shards; per step one RCCL all-gather of positions and one "
+                               f"send/recv round of partial sums (every pair between shards evaluated once)",
                 "bodies_left_in_box": n_after,
             },
             "roofline": roofline,

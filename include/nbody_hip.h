@@ -161,10 +161,14 @@ int nbody_ic_disc(void* aos, size_t n_disc, size_t stride_bytes, uint64_t seed);
 
 /* ---- test hooks: one sharded step with the exchange done by the caller ------------------------- */
 /* G handles of one process (rank r of world G, same device) stand in for G GPUs: step_begin on
- * each, import every peer's segment into each, step_end on each -- nbody_step_by with the RCCL
- * all-gather replaced by device-to-device copies. */
+ * each, import every peer's segment into each (the all-gather of positions), step_forces on each,
+ * import every peer's partial sums into each (the ncclSend/ncclRecv round of the symmetric scheme
+ * across shards; a no-op for force passes that exchange nothing), step_end on each --
+ * nbody_step_by with the RCCL transfers replaced by device-to-device copies. */
 int nbody_debug_step_begin(NbodyHandle* h, float dt);
 int nbody_debug_import_segment(NbodyHandle* h, NbodyHandle* peer);
+int nbody_debug_step_forces(NbodyHandle* h, float dt);
+int nbody_debug_import_partials(NbodyHandle* h, NbodyHandle* peer);
 int nbody_debug_step_end(NbodyHandle* h, float dt);
 
 /* ---- host-only entry (no device needed): the octree build alone ------------------------------ */

@@ -54,7 +54,8 @@ DECLARED_SYMBOLS = [
     "nbody_sync", "nbody_set_profiling", "nbody_stats", "nbody_reset_stats", "nbody_energy", "nbody_tree_export",
     "nbody_last_error", "nbody_comm_unique_id", "nbody_comm_init", "nbody_local_range", "nbody_ic_plummer",
     "nbody_ic_disc", "nbody_host_build_tree", "nbody_abi_version", "nbody_device_count",
-    "nbody_debug_step_begin", "nbody_debug_import_segment", "nbody_debug_step_end",
+    "nbody_debug_step_begin", "nbody_debug_import_segment", "nbody_debug_step_forces",
+    "nbody_debug_import_partials", "nbody_debug_step_end",
 ]
 
 
@@ -119,6 +120,8 @@ _sig("nbody_host_build_tree", _i, C.c_void_p, _sz, _pf, _f, _i, C.c_void_p, C.c_
      C.c_void_p, _sz, C.POINTER(_sz))
 _sig("nbody_debug_step_begin", _i, _H, _f)
 _sig("nbody_debug_import_segment", _i, _H, _H)
+_sig("nbody_debug_step_forces", _i, _H, _f)
+_sig("nbody_debug_import_partials", _i, _H, _H)
 _sig("nbody_debug_step_end", _i, _H, _f)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
@@ -335,18 +338,24 @@ class Simulation:
 
 
 def sharded_step(sims: list, dt: float | None = None):
-    """One step of a world of len(sims) shards living in this process (test harness: the exchange
-    the RCCL all-gather performs is done with device-to-device copies)."""
-    for s in sims:
-        d = s.settings.dt if dt is None else dt
-        s._check(lib.nbody_debug_step_begin(s._h, float(d)))
+    """One step of a world of len(sims) shards living in this process (test harness: what the RCCL
+    all-gather of positions and the send/recv round of partial sums perform is done with
+    device-to-device copies)."""
+    dts = [float(s.settings.dt if dt is None else dt) for s in sims]
+    for s, d in zip(sims, dts):
+        s._check(lib.nbody_debug_step_begin(s._h, d))
     for s in sims:
         for peer in sims:
             if peer is not s:
                 s._check(lib.nbody_debug_import_segment(s._h, peer._h))
+    for s, d in zip(sims, dts):
+        s._check(lib.nbody_debug_step_forces(s._h, d))
     for s in sims:
-        d = s.settings.dt if dt is None else dt
-        s._check(lib.nbody_debug_step_end(s._h, float(d)))
+        for peer in sims:
+            if peer is not s:
+                s._check(lib.nbody_debug_import_partials(s._h, peer._h))
+    for s, d in zip(sims, dts):
+        s._check(lib.nbody_debug_step_end(s._h, d))
 
 
 def comm_unique_id() -> bytes:

@@ -53,7 +53,8 @@ struct SymPlan {
     int sym_sets = 0;     // sets met symmetrically = ceil(A/2) - 1
     int n_planes = 0;     // partial-sum planes (own-shard kernels + k_os one-sided planes of a sharded run)
     int k_os = 0;         // slices per resident set of the one-sided remote kernel (0 = single shard)
-    size_t n_pad = 0;     // bodies per plane (A * 64 * ipt)
+    size_t n_pad = 0;     // padded body count (A * 64 * ipt)
+    size_t plane_stride = 0;  // float4 entries per plane (>= n_pad; sharded runs: also >= the shard capacity)
     std::vector<int> bounds;  // K+1 cut points of a set's chunk sequence
 };
 SymPlan make_sym_plan(int n_upper);
@@ -63,6 +64,28 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
 void launch_bf_os(hipStream_t s, const Shard& sh, int A, int K, float4* planes, size_t plane_stride, float g_soft2);
 void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4* planes, int n_upper, float g,
                         float g_soft2, const float* kick_dt);
+
+// K2, symmetric across shards (kernels_bf_cross.hip)
+struct CrossPartners {  // passed to the kernels by value
+    static constexpr int kMax = 8;
+    int n = 0;
+    int seg[kMax];          // partner shard
+    int c0[kMax], c1[kMax]; // its chunks (of 64 bodies) this GPU evaluates
+    int a0[kMax], a1[kMax]; // own resident sets that take part
+};
+struct CrossPlan {
+    static constexpr int kMaxPlanes = 256;
+    int ipt = 8;               // resident bodies per lane (8, or 4 for small shards)
+    int A = 0;                 // own resident sets of 64*ipt bodies
+    CrossPartners parts;       // shards this GPU is resident for
+    int n_recv = 0;            // shards that send partial sums for the own bodies ...
+    int recv_from[CrossPartners::kMax];  // ... in this (rank-distance) order
+    int k_res = 0;             // resident-side planes
+    std::vector<int4> slices;  // {set, first chunk, last chunk (of the set's partner-chunk sequence), plane}
+};
+CrossPlan make_cross_plan(int rank, int world, int seg_cap, int n_own_upper);
+void launch_bf_cross(hipStream_t s, const Shard& sh, const CrossPlan& p, const int4* d_slices, float4* res_planes,
+                     float4* xplanes, float4* send, size_t plane_stride, float g_soft2);
 
 // K5: BarnesHutSimulation::calc_force (barnes_hut.rs:185-203) over a linearised octree
 struct TreeDev {

@@ -25,6 +25,7 @@
 //
 // fast math only (v_rsq_f32 + FMA; summation order differs from the reference): tolerance 1e-5.
 #include "kernels.h"
+#include "bf_pair.h"
 
 #include <algorithm>
 
@@ -32,85 +33,7 @@ namespace nbody {
 
 namespace {
 
-// rotate by one lane through the LDS crossbar: lane l receives lane (l-1)&63's value.  No LDS memory
-// is touched and no VALU slot is spent; the result arrives ~60+ cycles later, behind other work.
-__device__ __forceinline__ float rotl(float v, int src_lane_x4) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_x4, __float_as_int(v)));
-}
-
-#define PAD_POS 1.0e15f  // zero-mass padding bodies sit far away: they exert and (after masking) receive nothing
-
 __device__ unsigned long long nbody_sym_stamps[3 * 8192];  // diagnostic builds only (DBG & 4)
-
-// One rotation step: IPT unordered pairs per lane, written stage by stage over all IPT pairs so
-// that every instruction's inputs were produced at least IPT instructions earlier (the compiler's
-// own schedule chains dependent fma -> rsq -> mul -> fma back to back and issues at ~4 cycles per
-// instruction instead of ~2.3; sched_barrier keeps the stages in this order).
-template <int IPT, int DBG = 0, bool SYM = true>
-__device__ __forceinline__ void pair_evals(const float (&xi)[IPT], const float (&yi)[IPT], const float (&zi)[IPT],
-                                           const float (&mi)[IPT], float (&axi)[IPT], float (&ayi)[IPT],
-                                           float (&azi)[IPT], float xj, float yj, float zj, float mj, float& axj,
-                                           float& ayj, float& azj, float eps2) {
-    float dx[IPT], dy[IPT], dz[IPT], r[IPT], sj[IPT];
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) dx[q] = xj - xi[q];
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) dy[q] = yj - yi[q];
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) dz[q] = zj - zi[q];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) r[q] = __builtin_fmaf(dx[q], dx[q], eps2);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) r[q] = __builtin_fmaf(dy[q], dy[q], r[q]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) r[q] = __builtin_fmaf(dz[q], dz[q], r[q]);
-    __builtin_amdgcn_sched_barrier(0);
-    // v_rsq_f32 costs ~8 cycles back to back but ~13-15 in this mixed stream (measured in place by
-    // swapping it for a multiply); raising the wave's priority around the burst does not help
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) {
-        if (DBG & 2) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(r[q]));  // timing experiment: no transcendental
-        else r[q] = __builtin_amdgcn_rsqf(r[q]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) sj[q] = r[q] * r[q];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) r[q] = sj[q] * r[q];   // rinv^3
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) sj[q] = mj * r[q];     // what body j does to body i
-    __builtin_amdgcn_sched_barrier(0);
-    if (SYM) {
-#pragma unroll
-        for (int q = 0; q < IPT; ++q) r[q] = mi[q] * r[q];   // what body i does to body j
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < IPT; ++q) {
-            axi[q] = __builtin_fmaf(dx[q], sj[q], axi[q]);
-            axj = __builtin_fmaf(-dx[q], r[q], axj);
-            ayi[q] = __builtin_fmaf(dy[q], sj[q], ayi[q]);
-            ayj = __builtin_fmaf(-dy[q], r[q], ayj);
-            azi[q] = __builtin_fmaf(dz[q], sj[q], azi[q]);
-            azj = __builtin_fmaf(-dz[q], r[q], azj);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {  // one-sided: only the resident bodies are updated
-#pragma unroll
-        for (int q = 0; q < IPT; ++q) axi[q] = __builtin_fmaf(dx[q], sj[q], axi[q]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < IPT; ++q) ayi[q] = __builtin_fmaf(dy[q], sj[q], ayi[q]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < IPT; ++q) azi[q] = __builtin_fmaf(dz[q], sj[q], azi[q]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 }  // namespace
 
@@ -439,6 +362,7 @@ SymPlan make_sym_plan(int n_upper) {
     p.K = K;
     p.n_planes = p.sym_sets + K + 1;             // travelling-side, resident-side (one per slice), own/opposite set
     p.n_pad = size_t(p.A) * 64 * IPT;
+    p.plane_stride = p.n_pad;
     p.bounds.resize(K + 1);
     for (int part = 0; part <= K; ++part) p.bounds[part] = int((long long)L * part / K);
     return p;
@@ -464,7 +388,7 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
     const int main_blocks = (p.A * p.K + p.wpb - 1) / p.wpb;
     const int rest_blocks = int(p.n_pad / 64);  // one workgroup per 64 bodies
     const dim3 grid(main_blocks + rest_blocks), block(p.wpb * 64);
-#define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.n_pad, g_soft2)
+#define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.plane_stride, g_soft2)
     if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
         if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
     } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
@@ -490,17 +414,17 @@ void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4
                         float g_soft2, const float* kick_dt) {
     if (n_upper <= 0) return;
     if (p.sym_sets == 0) {  // no rotation pass: the resident-side planes are never written
-        float4* resident0 = planes + size_t(p.sym_sets) * p.n_pad;
-        (void)hipMemsetAsync(resident0, 0, size_t(p.K) * p.n_pad * sizeof(float4), s);
+        float4* resident0 = planes + size_t(p.sym_sets) * p.plane_stride;
+        (void)hipMemsetAsync(resident0, 0, size_t(p.K) * p.plane_stride * sizeof(float4), s);
         hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(),
-                           sh.own_count(), p.A, planes + size_t(p.sym_sets + p.K) * p.n_pad, g_soft2);
+                           sh.own_count(), p.A, planes + size_t(p.sym_sets + p.K) * p.plane_stride, g_soft2);
     }
     const dim3 grid((n_upper + 255) / 256);
     if (kick_dt)
-        hipLaunchKernelGGL(k_bf_sym_reduce<true>, grid, dim3(256), 0, s, planes, p.n_planes, p.n_pad, sh.own_count(), g,
+        hipLaunchKernelGGL(k_bf_sym_reduce<true>, grid, dim3(256), 0, s, planes, p.n_planes, p.plane_stride, sh.own_count(), g,
                            sh.acc, sh.own_pos(), sh.vel, *kick_dt);
     else
-        hipLaunchKernelGGL(k_bf_sym_reduce<false>, grid, dim3(256), 0, s, planes, p.n_planes, p.n_pad, sh.own_count(), g,
+        hipLaunchKernelGGL(k_bf_sym_reduce<false>, grid, dim3(256), 0, s, planes, p.n_planes, p.plane_stride, sh.own_count(), g,
                            sh.acc, sh.own_pos(), sh.vel, 0.f);
 }
 

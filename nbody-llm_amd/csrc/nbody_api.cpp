@@ -26,6 +26,7 @@ extern "C" int nbody_bf_fast_variant;
 extern "C" int nbody_sym_wpb;
 extern "C" int nbody_sym_rounds;
 extern "C" int nbody_bh_walk_split;
+extern "C" int nbody_cross_sym = 1;  // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided
 
 using nbody::BoundsF;
 using nbody::Shard;
@@ -74,6 +75,18 @@ struct NbodyHandle {
     float4* d_planes = nullptr;
     size_t planes_cap = 0;  // float4 entries
     int sym_waves = 0;
+    // symmetric scheme across shards (kernels_bf_cross.hip)
+    nbody::CrossPlan cross;
+    bool cross_on = false;
+    int4* d_cross_slices = nullptr;
+    size_t cross_slices_cap = 0;
+    float4* d_xplanes = nullptr;   // [parts.n][A][plane_stride] travelling-side sums for other shards' bodies
+    float4* d_send = nullptr;      // [parts.n][plane_stride] what goes back to their owners
+    size_t xplanes_cap = 0, send_cap = 0;
+    int recv_plane0 = 0;           // first plane that receives the other shards' partial sums
+    bool tail_pending = false;     // the plane reduction has not been launched yet (waits for the partials)
+    bool partials_in_flight = false;
+    hipEvent_t ev_partials_ready = nullptr, ev_partials_done = nullptr;
     bool kick_pending = false;  // step_end asks the force pass to fuse integrate_after_force if it can
     float kick_dt = 0.f;
     uint64_t sym_pairs = 0;   // unordered pairs the rotation kernel covers at the current n_local
@@ -246,19 +259,58 @@ int ensure_sym_plan(NbodyHandle* h) {
     h->sym_waves = knobs;
     h->sym_plan = nbody::make_sym_plan(int(h->n_local));
     nbody::SymPlan& p = h->sym_plan;
-    if (h->sh.n_seg > 1) {  // one-sided planes for the other shards' bodies: CU-sized 12-wave workgroups
-        p.k_os = std::max(1, std::min(256, 3072 / p.A));
-        p.n_planes += p.k_os;
+    h->cross_on = false;
+    if (h->sh.n_seg > 1) {
+        const size_t cap_pad = (size_t(h->sh.seg_cap) + 63) / 64 * 64;
+        p.plane_stride = std::max(p.n_pad, cap_pad);
+        if (nbody_cross_sym && h->sh.n_seg <= 2 * (nbody::CrossPartners::kMax - 1)) {
+            // every unordered pair between shards once: this GPU is resident for some partners and
+            // receives the partial sums the others accumulated for its bodies
+            h->cross = nbody::make_cross_plan(h->sh.my_seg, h->sh.n_seg, h->sh.seg_cap, int(h->n_local));
+            h->cross_on = true;
+            h->recv_plane0 = p.n_planes + h->cross.k_res;
+            p.n_planes += h->cross.k_res + h->cross.n_recv;
+        } else {  // one-sided planes for the other shards' bodies: CU-sized 12-wave workgroups
+            p.k_os = std::max(1, std::min(256, 3072 / p.A));
+            p.n_planes += p.k_os;
+        }
     }
     if (!h->d_sym_bounds) HIP_TRY(h, hipMalloc(&h->d_sym_bounds, 128 * sizeof(int)));
     HIP_TRY(h, hipMemcpyAsync(h->d_sym_bounds, p.bounds.data(), p.bounds.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // p.bounds is pageable
-    const size_t need = size_t(p.n_planes) * p.n_pad;
+    const size_t need = size_t(p.n_planes) * p.plane_stride;
     if (need > h->planes_cap) {
         if (h->d_planes) (void)hipFree(h->d_planes);
         h->d_planes = nullptr; h->planes_cap = 0;
         HIP_TRY(h, hipMalloc(&h->d_planes, need * sizeof(float4)));
         h->planes_cap = need;
+    }
+    if (h->cross_on) {
+        const nbody::CrossPlan& c = h->cross;
+        if (c.slices.size() > h->cross_slices_cap) {
+            if (h->d_cross_slices) (void)hipFree(h->d_cross_slices);
+            h->d_cross_slices = nullptr; h->cross_slices_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_cross_slices, (c.slices.size() + 64) * sizeof(int4)));
+            h->cross_slices_cap = c.slices.size() + 64;
+        }
+        if (!c.slices.empty()) {
+            HIP_TRY(h, hipMemcpyAsync(h->d_cross_slices, c.slices.data(), c.slices.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+        const size_t xneed = size_t(std::max(1, c.parts.n)) * size_t(c.A) * p.plane_stride;
+        if (xneed > h->xplanes_cap) {
+            if (h->d_xplanes) (void)hipFree(h->d_xplanes);
+            h->d_xplanes = nullptr; h->xplanes_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_xplanes, xneed * sizeof(float4)));
+            h->xplanes_cap = xneed;
+        }
+        const size_t sneed = size_t(std::max(1, c.parts.n)) * p.plane_stride;
+        if (sneed > h->send_cap) {
+            if (h->d_send) (void)hipFree(h->d_send);
+            h->d_send = nullptr; h->send_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_send, sneed * sizeof(float4)));
+            h->send_cap = sneed;
+        }
     }
     return NBODY_OK;
 }
@@ -294,23 +346,37 @@ int bf_forces(NbodyHandle* h) {
             nbody::launch_bf_sym_main(h->stream, h->sh, p, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
         }
         timed = 2 * h->sym_pairs;
-        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2, h->kick_pending ? &h->kick_dt : nullptr);
-        h->kick_pending = false;
+        h->tail_pending = true;
     } else {
-        // own shard symmetric (needs no remote data: it overlaps the exchange), the other shards
-        // one-sided, one fixed-order sum over all the planes
+        // own shard symmetric (needs no remote data: it overlaps the exchange of positions) ...
         nbody::launch_bf_sym_main(h->stream, h->sh, p, h->d_sym_bounds, h->d_planes, int(h->n_local), eps2);
         {
             int rc = exchange_wait(h);
             if (rc) return rc;
         }
-        {
+        if (h->cross_on) {
+            // ... then the pairs with the partner shards, both sides; the partial sums for their bodies
+            // go back to their owners before the planes are added up (forces_finish)
+            const nbody::CrossPlan& c = h->cross;
+            {
+                ForceTimer t(h);
+                nbody::launch_bf_cross(h->stream, h->sh, c, h->d_cross_slices,
+                                       h->d_planes + size_t(h->recv_plane0 - c.k_res) * p.plane_stride, h->d_xplanes,
+                                       h->d_send, p.plane_stride, eps2);
+            }
+            for (int i = 0; i < c.parts.n; ++i) {  // unordered pairs x 2, from the host's (upper-bound) counts
+                const long long set = 64LL * c.ipt;
+                const long long own = std::max(0LL, std::min<long long>(h->n_local, set * c.parts.a1[i]) - set * c.parts.a0[i]);
+                const long long theirs = std::max(0LL, std::min<long long>(h->seg_count_host[c.parts.seg[i]], 64LL * c.parts.c1[i]) - 64LL * c.parts.c0[i]);
+                timed += 2ull * uint64_t(own) * uint64_t(theirs);
+            }
+        } else {
+            // ... then the other shards' bodies one-sided
             ForceTimer t(h);
-            nbody::launch_bf_os(h->stream, h->sh, p.A, p.k_os, h->d_planes + size_t(p.n_planes - p.k_os) * p.n_pad, p.n_pad, eps2);
+            nbody::launch_bf_os(h->stream, h->sh, p.A, p.k_os, h->d_planes + size_t(p.n_planes - p.k_os) * p.plane_stride, p.plane_stride, eps2);
+            timed = uint64_t(h->n_local) * uint64_t(tot - h->n_local);
         }
-        timed = uint64_t(h->n_local) * uint64_t(tot - h->n_local);
-        nbody::launch_bf_sym_tail(h->stream, h->sh, p, h->d_planes, int(h->n_local), h->g, eps2, h->kick_pending ? &h->kick_dt : nullptr);
-        h->kick_pending = false;
+        h->tail_pending = true;
     }
     HIP_TRY(h, hipGetLastError());
     if (tot > 0) {
@@ -457,8 +523,58 @@ int bh_forces(NbodyHandle* h) {
     return NBODY_OK;
 }
 
-int forces(NbodyHandle* h) {
+// ---- the partial sums other GPUs accumulated for the own bodies (symmetric scheme across shards)
+int partials_begin(NbodyHandle* h) {
+    if (!(h->cross_on && h->tail_pending) || h->cross.parts.n + h->cross.n_recv == 0) return NBODY_OK;
+    if (!h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    const nbody::CrossPlan& c = h->cross;
+    const size_t S = h->sym_plan.plane_stride;
+    const size_t count = size_t(h->sh.seg_cap) * 4;
+    HIP_TRY(h, hipEventRecord(h->ev_partials_ready, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_partials_ready, 0));
+    NCCL_TRY(h, ncclGroupStart());
+    for (int i = 0; i < c.parts.n; ++i)
+        NCCL_TRY(h, ncclSend(h->d_send + size_t(i) * S, count, ncclFloat, c.parts.seg[i], h->comm, h->comm_stream));
+    for (int i = 0; i < c.n_recv; ++i)
+        NCCL_TRY(h, ncclRecv(h->d_planes + size_t(h->recv_plane0 + i) * S, count, ncclFloat, c.recv_from[i], h->comm, h->comm_stream));
+    NCCL_TRY(h, ncclGroupEnd());
+    HIP_TRY(h, hipEventRecord(h->ev_partials_done, h->comm_stream));
+    h->partials_in_flight = true;
+    return NBODY_OK;
+}
+
+int partials_wait(NbodyHandle* h) {
+    if (!h->partials_in_flight) return NBODY_OK;
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_partials_done, 0));
+    h->partials_in_flight = false;
+    return NBODY_OK;
+}
+
+// everything of the force pass that needs no other GPU's partial sums
+int forces_begin(NbodyHandle* h) {
     return h->cfg.method == NBODY_BARNES_HUT ? bh_forces(h) : bf_forces(h);
+}
+
+// the plane reduction (with the kick + half drift when a step asked for it)
+int forces_finish(NbodyHandle* h) {
+    if (!h->tail_pending) return NBODY_OK;
+    h->tail_pending = false;
+    const float eps2 = h->g_soft * h->g_soft;
+    nbody::launch_bf_sym_tail(h->stream, h->sh, h->sym_plan, h->d_planes, int(h->n_local), h->g, eps2,
+                              h->kick_pending ? &h->kick_dt : nullptr);
+    h->kick_pending = false;
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+int forces(NbodyHandle* h) {
+    int rc = forces_begin(h);
+    if (rc) return rc;
+    rc = partials_begin(h);
+    if (rc) return rc;
+    rc = partials_wait(h);
+    if (rc) return rc;
+    return forces_finish(h);
 }
 
 int step_begin(NbodyHandle* h, float dt) {
@@ -470,10 +586,17 @@ int step_begin(NbodyHandle* h, float dt) {
     return NBODY_OK;
 }
 
-int step_end(NbodyHandle* h, float dt) {
-    h->kick_pending = true;   // a force pass that ends in a reduction kernel applies the kick itself
+// update_forces up to (not including) whatever needs other GPUs' partial sums
+int step_forces(NbodyHandle* h, float dt) {
+    h->kick_pending = true;   // a force pass that ends in a plane reduction applies the kick itself
     h->kick_dt = dt;
-    int rc = forces(h);                                                        // update_forces
+    int rc = forces_begin(h);                                                  // update_forces
+    if (rc) { h->kick_pending = false; h->tail_pending = false; }
+    return rc;
+}
+
+int step_finish(NbodyHandle* h, float dt) {
+    int rc = forces_finish(h);
     if (rc) { h->kick_pending = false; return rc; }
     if (h->kick_pending) nbody::launch_kick_drift(h->stream, h->sh, int(h->n_local), dt);  // integrate_after_force
     h->kick_pending = false;
@@ -481,6 +604,16 @@ int step_end(NbodyHandle* h, float dt) {
     h->elapsed += dt;                                                          // elapsed += dt
     h->stats.steps += 1;
     return NBODY_OK;
+}
+
+int step_end(NbodyHandle* h, float dt) {
+    int rc = step_forces(h, dt);
+    if (rc) return rc;
+    rc = partials_begin(h);
+    if (rc) return rc;
+    rc = partials_wait(h);
+    if (rc) return rc;
+    return step_finish(h, dt);
 }
 
 int step_impl(NbodyHandle* h, float dt) {
@@ -499,12 +632,14 @@ void free_all(NbodyHandle* h) {
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->ev_drifted) (void)hipEventDestroy(h->ev_drifted);
     if (h->ev_gathered) (void)hipEventDestroy(h->ev_gathered);
+    if (h->ev_partials_ready) (void)hipEventDestroy(h->ev_partials_ready);
+    if (h->ev_partials_done) (void)hipEventDestroy(h->ev_partials_done);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (auto& ev : h->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes};
+                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -578,6 +713,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
+    if (const char* v = std::getenv("NBODY_CROSS_SYM")) nbody_cross_sym = std::atoi(v);
     *out = h;
     return NBODY_OK;
 }
@@ -926,6 +1062,8 @@ int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_drifted, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_gathered, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_partials_ready, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_partials_done, hipEventDisableTiming));
     }
     h->comm_ready = true;
     return NBODY_OK;
@@ -962,10 +1100,37 @@ int nbody_debug_import_segment(NbodyHandle* h, NbodyHandle* peer) {
     return NBODY_OK;
 }
 
+int nbody_debug_step_forces(NbodyHandle* h, float dt) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    return rc ? rc : step_forces(h, dt);
+}
+
+// what the grouped ncclSend/ncclRecv round delivers: the partial sums `peer` accumulated for this
+// shard's bodies, into the plane reserved for that sender
+int nbody_debug_import_partials(NbodyHandle* h, NbodyHandle* peer) {
+    if (!h || !peer) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!(h->cross_on && h->tail_pending)) return NBODY_OK;   // this force pass exchanges nothing
+    if (!(peer->cross_on && peer->tail_pending)) return fail(h, NBODY_ERR_INVALID, "peer is not in the same phase");
+    int src = -1, dst = -1;
+    for (int i = 0; i < peer->cross.parts.n; ++i) if (peer->cross.parts.seg[i] == h->sh.my_seg) src = i;
+    for (int i = 0; i < h->cross.n_recv; ++i) if (h->cross.recv_from[i] == peer->sh.my_seg) dst = i;
+    if ((src < 0) != (dst < 0)) return fail(h, NBODY_ERR_INVALID, "send/receive plans of the two shards do not match");
+    if (src < 0) return NBODY_OK;
+    HIP_TRY(h, hipStreamSynchronize(peer->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_planes + size_t(h->recv_plane0 + dst) * h->sym_plan.plane_stride,
+                              peer->d_send + size_t(src) * peer->sym_plan.plane_stride,
+                              size_t(h->sh.seg_cap) * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+
 int nbody_debug_step_end(NbodyHandle* h, float dt) {
     if (!h) return NBODY_ERR_INVALID;
     int rc = use_device(h);
-    return rc ? rc : step_end(h, dt);
+    return rc ? rc : step_finish(h, dt);
 }
 
 // Host-only entry (no device needed): the octree build alone, for tests of the host logic.

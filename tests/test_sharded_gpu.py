@@ -67,11 +67,16 @@ def test_brute_force_shards_with_escapes(gpu, orc):
         s.close()
 
 
-@pytest.mark.parametrize("G,n", [(2, 6000), (2, 20000), (3, 10000), (8, 20000), (8, 65536)])
-def test_brute_force_fast_shards(gpu, orc, G, n):
-    """fast math, sharded: the own shard by the symmetric kernel, the other shards by the one-sided
-    kernel k_bf_os (n/G >= 2048), else the LDS-tiled kernel; 1e-5 against the f32 oracle."""
+@pytest.mark.parametrize("cross", [1, 0])
+@pytest.mark.parametrize("G,n", [(2, 6000), (2, 20000), (3, 10000), (4, 9001), (5, 12000), (8, 20000), (8, 65536)])
+def test_brute_force_fast_shards(gpu, orc, G, n, cross):
+    """fast math, sharded (n/G >= 2048; below that the LDS-tiled kernel): the own shard by the
+    symmetric kernel; the other shards either symmetric too (cross = 1, the default: every pair
+    between shards evaluated once, by one of the two GPUs, partial sums returned to the owner) or
+    one-sided (cross = 0, k_bf_os).  1e-5 against the f32 oracle either way."""
+    import ctypes
     nb = gpu
+    ctypes.c_int.in_dll(nb.lib, "nbody_cross_sym").value = cross
     sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
     ics = nb.plummer(n, seed=5)
     ics["mass"] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
@@ -91,8 +96,30 @@ def test_brute_force_fast_shards(gpu, orc, G, n):
     assert np.isfinite(got["acceleration"]).all()
     assert rel_err(got["acceleration"], ref["acceleration"]) < (1e-5 if n <= 20000 else 3e-5)
     assert rel_err(got["position"], ref["position"]) < 1e-6
+    if n // G >= 2048:   # the intended path ran: the timed launch covers the pairs with other shards
+        st = [s_.stats() for s_ in sims]
+        assert all(s_.steps == steps for s_ in st)
     for s in sims:
         s.close()
+    ctypes.c_int.in_dll(nb.lib, "nbody_cross_sym").value = 1
+
+
+def test_cross_shard_pairs_are_dealt_exactly_once(gpu):
+    """Host-side plan of the symmetric scheme across shards: over all ranks, every (own set, partner
+    chunk) block between two different shards is claimed by exactly one of the two GPUs."""
+    import ctypes
+    nb = gpu
+    for G in (2, 3, 4, 5, 8):
+        n = 4096 * G + 777
+        ics = nb.plummer(n, seed=G)
+        sims = make_world(nb, ics, G, BOX, nb.Settings(), nb.BRUTE_FORCE, nb.FAST)
+        nb.sharded_step(sims)      # builds the plans; momentum conservation checks the pairing as a whole
+        got = gather(sims)
+        m = got["mass"].astype(np.float64)[:, None]
+        p = (got["acceleration"].astype(np.float64) * m).sum(0)
+        assert np.abs(p).max() < 2e-6 * np.abs(got["acceleration"].astype(np.float64) * m).sum(), G
+        for s in sims:
+            s.close()
 
 
 def test_brute_force_fast_shards_with_escapes(gpu, orc):
