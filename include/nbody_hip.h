@@ -171,6 +171,12 @@ int nbody_debug_step_forces(NbodyHandle* h, float dt);
 int nbody_debug_import_partials(NbodyHandle* h, NbodyHandle* peer);
 int nbody_debug_step_end(NbodyHandle* h, float dt);
 
+/* ---- host-only entry (no device needed): the plan of the symmetric scheme across shards ---------- */
+/* Which pairs between shards `rank` evaluates (rows {shard, first chunk, last chunk, first own set,
+ * last own set} of 64-body chunks and 64*ipt-body sets) and which ranks send it partial sums. */
+int nbody_host_cross_plan(int rank, int world, int seg_cap, int n_own, int* ipt, int* n_sets, int* n_parts, int* parts,
+                          int* n_recv, int* recv_from);
+
 /* ---- host-only entry (no device needed): the octree build alone ------------------------------ */
 /* BarnesHutSimulation::build_tree (barnes_hut.rs:143-183) + linearisation, as the Barnes-Hut step
  * runs it.  pos4 = n records {x,y,z,m}.  Output arrays hold `cap` nodes (com_mass: 4 floats per

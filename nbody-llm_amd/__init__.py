@@ -55,7 +55,7 @@ DECLARED_SYMBOLS = [
     "nbody_last_error", "nbody_comm_unique_id", "nbody_comm_init", "nbody_local_range", "nbody_ic_plummer",
     "nbody_ic_disc", "nbody_host_build_tree", "nbody_abi_version", "nbody_device_count",
     "nbody_debug_step_begin", "nbody_debug_import_segment", "nbody_debug_step_forces",
-    "nbody_debug_import_partials", "nbody_debug_step_end",
+    "nbody_debug_import_partials", "nbody_debug_step_end", "nbody_host_cross_plan",
 ]
 
 
@@ -123,6 +123,8 @@ _sig("nbody_debug_import_segment", _i, _H, _H)
 _sig("nbody_debug_step_forces", _i, _H, _f)
 _sig("nbody_debug_import_partials", _i, _H, _H)
 _sig("nbody_debug_step_end", _i, _H, _f)
+_sig("nbody_host_cross_plan", _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_void_p, C.POINTER(_i),
+     C.c_void_p)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
 
@@ -356,6 +358,18 @@ def sharded_step(sims: list, dt: float | None = None):
                 s._check(lib.nbody_debug_import_partials(s._h, peer._h))
     for s, d in zip(sims, dts):
         s._check(lib.nbody_debug_step_end(s._h, d))
+
+
+def host_cross_plan(rank: int, world: int, seg_cap: int, n_own: int) -> dict:
+    """Host-only: the plan of the symmetric scheme across shards for one rank."""
+    ipt, a, npart, nrecv = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    parts = np.zeros((8, 5), np.int32)
+    recv = np.zeros(8, np.int32)
+    rc = lib.nbody_host_cross_plan(rank, world, seg_cap, n_own, C.byref(ipt), C.byref(a), C.byref(npart),
+                                   parts.ctypes.data, C.byref(nrecv), recv.ctypes.data)
+    if rc:
+        raise NbodyError(rc, "nbody_host_cross_plan")
+    return dict(ipt=ipt.value, n_sets=a.value, parts=parts[: npart.value].copy(), recv_from=recv[: nrecv.value].copy())
 
 
 def comm_unique_id() -> bytes:

@@ -140,8 +140,12 @@ CrossPlan make_cross_plan(int rank, int G, int seg_cap, int n_own_upper) {
     const int IPT = (visits8 < 4 * 3072) ? 4 : 8;
     p.ipt = IPT;
     p.A = (n_own_upper + 64 * IPT - 1) / (64 * IPT);
-    const int split_chunk = std::min(chunks_cap, ((chunks_cap + 7) / 8 + 1) / 2 * 8);  // a multiple of 8 chunks
-    const int split_set = split_chunk / IPT;                    // opposite ranks: the higher rank's sets from here on
+    // opposite ranks: the lower rank takes the higher rank's chunks below `split`, the higher rank keeps
+    // its own sets from split/IPT on resident (a multiple of 8 chunks, so a set boundary for IPT 4 and 8;
+    // NOT clipped to the capacity: when it lies beyond it the lower rank simply takes everything)
+    const int split = ((chunks_cap + 7) / 8 + 1) / 2 * 8;
+    const int split_chunk = std::min(chunks_cap, split);
+    const int split_set = split / IPT;
     CrossPartners& q = p.parts;
     q.n = 0;
     auto add = [&](int seg, int c0, int c1, int a0, int a1) {

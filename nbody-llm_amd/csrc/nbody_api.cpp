@@ -1133,6 +1133,27 @@ int nbody_debug_step_end(NbodyHandle* h, float dt) {
     return rc ? rc : step_finish(h, dt);
 }
 
+// Host-only entry (no device needed): which pairs between shards this rank evaluates and whom it
+// exchanges partial sums with (kernels_bf_cross.hip make_cross_plan), for tests of the host logic.
+// parts: n_parts rows {shard, c0, c1, a0, a1}; recv_from: n_recv ranks in the order their planes are added.
+int nbody_host_cross_plan(int rank, int world, int seg_cap, int n_own, int* ipt, int* n_sets, int* n_parts, int* parts,
+                          int* n_recv, int* recv_from) {
+    if (world < 2 || rank < 0 || rank >= world || seg_cap <= 0 || n_own < 0 || n_own > seg_cap) return NBODY_ERR_INVALID;
+    if (world > 2 * (nbody::CrossPartners::kMax - 1)) return NBODY_ERR_INVALID;
+    const nbody::CrossPlan p = nbody::make_cross_plan(rank, world, seg_cap, n_own);
+    if (ipt) *ipt = p.ipt;
+    if (n_sets) *n_sets = p.A;
+    if (n_parts) *n_parts = p.parts.n;
+    if (parts)
+        for (int i = 0; i < p.parts.n; ++i) {
+            parts[5 * i + 0] = p.parts.seg[i]; parts[5 * i + 1] = p.parts.c0[i]; parts[5 * i + 2] = p.parts.c1[i];
+            parts[5 * i + 3] = p.parts.a0[i]; parts[5 * i + 4] = p.parts.a1[i];
+        }
+    if (n_recv) *n_recv = p.n_recv;
+    if (recv_from) for (int i = 0; i < p.n_recv; ++i) recv_from[i] = p.recv_from[i];
+    return NBODY_OK;
+}
+
 // Host-only entry (no device needed): the octree build alone, for tests of the host logic.
 // Arrays hold `cap` nodes (com_mass 4 floats per node); order holds n body ids.
 int nbody_host_build_tree(const float* pos4, size_t n, const float center[3], float width, int threads,

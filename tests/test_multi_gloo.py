@@ -63,6 +63,22 @@ def _worker(rank, world, port, n, steps, out_dir):
         orc.bf_update_forces_range(allb, sd, first, first + len(own), threads=1)
         own["acceleration"] = allb["acceleration"][first: first + len(own)]
         orc.after_force(own, sd["dt"])                              # K3
+    # the send/recv round of the symmetric scheme across shards, with the plan the library uses
+    # (nbody_host_cross_plan): one message to every shard this rank is resident for, one from every
+    # shard that is resident for it -- must complete (no deadlock) and deliver the right senders' data
+    plan = nb.host_cross_plan(rank, world, cap, hi - lo)
+    ops, bufs = [], []
+    for seg in plan["parts"][:, 0]:
+        ops.append(dist.P2POp(dist.isend, torch.full((cap * 4,), float(rank * 100 + int(seg))), int(seg)))
+    for src in plan["recv_from"]:
+        b = torch.zeros(cap * 4)
+        bufs.append((int(src), b))
+        ops.append(dist.P2POp(dist.irecv, b, int(src)))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for src, b in bufs:
+        assert torch.all(b == float(src * 100 + rank)), (rank, src)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), own)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)        # max-over-ranks like bench.py
     g = [torch.zeros_like(t) for _ in range(world)]
@@ -72,7 +88,7 @@ def _worker(rank, world, port, n, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_scheme_equals_unsharded_oracle(tmp_path, nb, orc, world):
     # ranks are plain child processes (this pytest process never imports torch: see conftest.nb)
     import subprocess
