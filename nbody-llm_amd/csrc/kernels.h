@@ -49,7 +49,9 @@ struct SymPlan {
     int ipt = 8;          // resident bodies per lane
     int A = 0;            // resident sets of 64*ipt bodies
     int K = 0;            // waves per resident set
-    int wpb = 16;         // waves per workgroup (16: one workgroup per CU, 12: two)
+    int wpb = 16;         // waves per workgroup (CU-sized: 12 by default)
+    int res_combine = 0;  // 1: K % wpb == 0, resident-side sums of a workgroup are combined in LDS
+    int k_res = 0;        // resident-side planes (K, or K / wpb when combined)
     int sym_sets = 0;     // sets met symmetrically = ceil(A/2) - 1
     int n_planes = 0;     // partial-sum planes (own-shard kernels + k_os one-sided planes of a sharded run)
     int k_os = 0;         // slices per resident set of the one-sided remote kernel (0 = single shard)

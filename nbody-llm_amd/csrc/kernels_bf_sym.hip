@@ -52,7 +52,8 @@ __device__ __forceinline__ void sym_rest_block(const float4* __restrict__ pos, i
 template <int IPT, int WPB, int DBG = 0>
 __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ pos, const int* __restrict__ count,
                                                      int A, int K, const int* __restrict__ bounds, int sym_sets,
-                                                     float4* __restrict__ planes, size_t plane_stride, float eps2) {
+                                                     float4* __restrict__ planes, size_t plane_stride, float eps2,
+                                                     int res_combine) {
     const int lane = threadIdx.x & 63;
     // Slices of a set differ by one chunk (e.g. 15,16,16,16,15,...).  A workgroup's waves land on the
     // SIMDs cyclically (wave w on SIMD w % 4, observed via HW_ID), so slices are dealt such that each
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
         // tail filler: the workgroups after the rotation workgroups are dispatched as CUs fall free
         // and do the own-set / opposite-set pairs (64 bodies per workgroup) inside the same launch
         __shared__ float red[WPB - 1][3][64];
-        sym_rest_block<IPT, WPB>(pos, *count, A, blockIdx.x - n_main_blocks, planes + size_t(sym_sets + K) * plane_stride, eps2, red);
+        sym_rest_block<IPT, WPB>(pos, *count, A, blockIdx.x - n_main_blocks,
+                                 planes + size_t(sym_sets + (res_combine ? K / WPB : K)) * plane_stride, eps2, red);
         return;
     }
     const int gw = blockIdx.x * WPB + (wslot & 3) * (WPB / 4) + (wslot >> 2);  // global slice index
@@ -145,6 +147,32 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
             const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
             nbody_sym_stamps[gw * 3 + 2] = (unsigned long long)(k1 - k0) | ((unsigned long long)hw << 16) | ((unsigned long long)(xcc & 0xF) << 48);
         }
+    }
+    if (res_combine) {
+        // K is a multiple of WPB: the workgroup's waves are WPB consecutive slices of ONE set; their
+        // resident-side sums are added in slice order through LDS and leave as one plane row set
+        __shared__ float comb[WPB - 1][3 * IPT][64];
+        const int first_part = (part / WPB) * WPB;
+        const int rel = part - first_part;       // 0 .. WPB-1
+        if (rel > 0) {
+#pragma unroll
+            for (int q = 0; q < IPT; ++q) {
+                comb[rel - 1][3 * q + 0][lane] = axi[q];
+                comb[rel - 1][3 * q + 1][lane] = ayi[q];
+                comb[rel - 1][3 * q + 2][lane] = azi[q];
+            }
+        }
+        __syncthreads();
+        if (rel == 0) {
+            float4* __restrict__ out = planes + size_t(sym_sets + part / WPB) * plane_stride;
+#pragma unroll
+            for (int q = 0; q < IPT; ++q) {
+                float sx = axi[q], sy = ayi[q], sz = azi[q];
+                for (int w = 0; w < WPB - 1; ++w) { sx += comb[w][3 * q + 0][lane]; sy += comb[w][3 * q + 1][lane]; sz += comb[w][3 * q + 2][lane]; }
+                out[size_t(a * IPT + q) * 64 + lane] = make_float4(sx, sy, sz, 0.f);
+            }
+        }
+        return;
     }
     // resident side: one plane per slice index
     float4* __restrict__ out = planes + size_t(sym_sets + part) * plane_stride;
@@ -360,7 +388,9 @@ SymPlan make_sym_plan(int n_upper) {
     if (K > L) K = L;
     if (K < 1) K = 1;
     p.K = K;
-    p.n_planes = p.sym_sets + K + 1;             // travelling-side, resident-side (one per slice), own/opposite set
+    p.res_combine = (K % p.wpb == 0) ? 1 : 0;    // a workgroup = wpb slices of one set: one resident plane per workgroup
+    p.k_res = p.res_combine ? K / p.wpb : K;
+    p.n_planes = p.sym_sets + p.k_res + 1;       // travelling-side, resident-side, own/opposite set
     p.n_pad = size_t(p.A) * 64 * IPT;
     p.plane_stride = p.n_pad;
     p.bounds.resize(K + 1);
@@ -388,7 +418,7 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
     const int main_blocks = (p.A * p.K + p.wpb - 1) / p.wpb;
     const int rest_blocks = int(p.n_pad / 64);  // one workgroup per 64 bodies
     const dim3 grid(main_blocks + rest_blocks), block(p.wpb * 64);
-#define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.plane_stride, g_soft2)
+#define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.plane_stride, g_soft2, p.res_combine)
     if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
         if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
     } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
@@ -415,9 +445,9 @@ void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4
     if (n_upper <= 0) return;
     if (p.sym_sets == 0) {  // no rotation pass: the resident-side planes are never written
         float4* resident0 = planes + size_t(p.sym_sets) * p.plane_stride;
-        (void)hipMemsetAsync(resident0, 0, size_t(p.K) * p.plane_stride * sizeof(float4), s);
+        (void)hipMemsetAsync(resident0, 0, size_t(p.k_res) * p.plane_stride * sizeof(float4), s);
         hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(),
-                           sh.own_count(), p.A, planes + size_t(p.sym_sets + p.K) * p.plane_stride, g_soft2);
+                           sh.own_count(), p.A, planes + size_t(p.sym_sets + p.k_res) * p.plane_stride, g_soft2);
     }
     const dim3 grid((n_upper + 255) / 256);
     if (kick_dt)
