@@ -117,10 +117,11 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
 // its own sequential walk would visit it; the wave steps to i + 1 while any lane still wants the
 // children, else to the skip link.  Per lane the accepted nodes, their order and the counters are
 // exactly those of k_bh_walk (and of the reference recursion); only the memory access pattern
-// changes.  With one wave per SIMD (N = 65 536 is only 1 024 waves) the dependent scalar-load chain is
-// exposed, so this form is slower than k_bh_walk today (1.26 vs 0.83 ms); it needs the node range
-// split over several waves per body group to pay off (Barnes-Hut, next steps).
-template <bool FAST, int LOADMODE>
+// changes.  Measured at N = 65 536, theta = 0.5 with the node range split 8 ways: 0.60 ms against 0.53
+// for the per-lane walk -- the union of 64 neighbours' node sequences is several times longer than one
+// body's, which costs more than the divergent gathers it saves (groups of 4/8/16/32 lanes were tried
+// too: 0.60/0.63/0.68/0.77 ms).  Kept as a selectable variant (nbody_bh_walk_variant = 1).
+template <bool FAST>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __restrict__ nodes, int n_nodes,
                                                              const int* __restrict__ order, int n_order,
                                                              const float4* __restrict__ own_pos,
@@ -137,23 +138,16 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
     unsigned int n_acc = 0, n_vis = 0;
     // dead lanes never look at a node; live ones start where their own walk enters this segment
     int resume = live ? walk_entry(nodes, split, seg, p, theta2) : 0x7fffffff;
-    int vzero = 0;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // an opaque per-lane zero keeps the load on the vector path
     int i = s0;                          // wave-uniform node index
     while (i < s1) {
         // uniform address: ONE 32-byte scalar load (left to itself the compiler fetches the mass in a
         // third, dependent s_load under the accept branch)
-        float4 A, B;
-        if (LOADMODE == 0) {
-            f32x8 rec;
-            asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(nodes + i) : "memory");
-            A = make_float4(rec[0], rec[1], rec[2], rec[3]);
-            B = make_float4(rec[4], rec[5], rec[6], rec[7]);
-        } else {  // same address in every lane through the vector path: one L1 line, broadcast
-            const NodeDev* pn = nodes + (i + vzero);
-            A = pn->a;
-            B = pn->b;
-        }
+        // uniform address: ONE 32-byte scalar load (left to itself the compiler fetches the mass in a
+        // third, dependent s_load under the accept branch)
+        f32x8 rec;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(nodes + i) : "memory");
+        const float4 A = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        const float4 B = make_float4(rec[4], rec[5], rec[6], rec[7]);
         const bool active = i >= resume;
         const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
         const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
@@ -214,8 +208,7 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
     dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
-    if (nbody_bh_walk_variant == 1) { if (fast_math) WALK(k_bh_walk_wave, true, 0); else WALK(k_bh_walk_wave, false, 0); }
-    else if (nbody_bh_walk_variant == 2) { if (fast_math) WALK(k_bh_walk_wave, true, 1); else WALK(k_bh_walk_wave, false, 1); }
+    if (nbody_bh_walk_variant == 1) { if (fast_math) WALK(k_bh_walk_wave, true); else WALK(k_bh_walk_wave, false); }
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
     if (t.n_split > 1)
