@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--n", type=int, default=65536, help="bodies over all GPUs")
     ap.add_argument("--math", choices=["fast", "strict"], default="fast")
     ap.add_argument("--theta", type=float, default=0.5, help="Barnes-Hut opening angle (theta2 = theta^2)")
+    ap.add_argument("--tree", choices=["host", "device"], default="host",
+                    help="Barnes-Hut octree build: host (north_star, bit-exact) or device (SURVEY F3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20250523)
     return ap.parse_args()
@@ -128,7 +130,8 @@ def main():
     math_mode = nb.FAST if args.math == "fast" else nb.STRICT
 
     sim = nb.Simulation(ics, *box, method=method, math_mode=math_mode, capacity=n, device=local_rank,
-                        rank=rank, world_size=world)
+                        rank=rank, world_size=world,
+                        tree_build=nb.TREE_DEVICE if args.tree == "device" else nb.TREE_HOST)
     sim.settings = nb.Settings(**st)
     if dist is not None and (world > 1 or os.environ.get("NBODY_BENCH_FORCE_COMM")):
         ident = [nb.comm_unique_id() if rank == 0 else None]
@@ -230,7 +233,7 @@ def main():
             "roofline": roofline,
         }
         if args.workload == "bh":
-            result["bh"] = {"tree_nodes": int(stats.tree_nodes), "node_visits_per_step": visits / args.steps,
+            result["bh"] = {"tree_build": args.tree, "tree_nodes": int(stats.tree_nodes), "node_visits_per_step": visits / args.steps,
                             "tree_build_ms_per_step": stats.tree_build_ms / args.steps,
                             "tree_copy_ms_per_step": stats.tree_copy_ms / args.steps}
     sim.close()

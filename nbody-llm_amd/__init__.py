@@ -38,6 +38,7 @@ NBODY_ERR_NO_DEVICE = -6
 BRUTE_FORCE, BARNES_HUT = 0, 1
 STRICT, FAST = 0, 1
 LEAF_REFERENCE = 0
+TREE_HOST, TREE_DEVICE = 0, 1
 COMM_ID_BYTES = 128
 
 #: PointParticle<f32,3>, #[repr(C)] (src/shared.rs:151-158)
@@ -63,7 +64,7 @@ class NbodyConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("method", C.c_int32), ("math_mode", C.c_int32), ("leaf_mode", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("host_threads", C.c_int32),
-        ("capacity", C.c_uint64),
+        ("capacity", C.c_uint64), ("tree_build", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -197,14 +198,14 @@ class Simulation:
 
     def __init__(self, points: np.ndarray, center=(0.0, 0.0, 0.0), width: float = 1.0, *, method: int = BRUTE_FORCE,
                  math_mode: int = STRICT, capacity: int | None = None, device: int = -1, rank: int = 0,
-                 world_size: int = 1, host_threads: int = 0, _handle=None):
+                 world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_HOST, _handle=None):
         self._h = _H()
         if _handle is not None:
             self._h = _handle
             return
         points = np.ascontiguousarray(points, dtype=PARTICLE_DTYPE)
         cfg = NbodyConfig(C.sizeof(NbodyConfig), method, math_mode, LEAF_REFERENCE, device, rank, world_size,
-                          host_threads, int(capacity if capacity is not None else max(1, points.shape[0])))
+                          host_threads, int(capacity if capacity is not None else max(1, points.shape[0])), tree_build, 0)
         rc = lib.nbody_create(C.byref(cfg), C.byref(self._h))
         if rc:
             self._h = _H()

@@ -103,6 +103,19 @@ struct TreeDev {
     float4* split_planes = nullptr;     // [n_split][split_stride]
     size_t split_stride = 0;
 };
+// device-side octree build (kernels_tree.hip)
+struct TreeDevWork {  // arrays of the last build the split-point kernel needs
+    const unsigned long long* keys = nullptr;
+    const signed char* delta = nullptr;
+    const int* base = nullptr;
+};
+size_t tree_build_workspace_bytes(size_t n_cap);
+int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
+                        float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
+                        int* out_info, TreeDevWork* work);
+void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
+                           int* n_anc, int* anc, int max_anc);
+
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters /* [2]: accepted, visited */);
 

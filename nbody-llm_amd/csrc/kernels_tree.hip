@@ -1,0 +1,254 @@
+// kernels_tree.hip -- device-side octree build, the fast-math alternative to
+// octree_host.cpp.  Produces the SAME cells, pre-order and skip links as
+// BarnesHutSimulation::build_tree (src/manual/barnes_hut.rs:143-183); only the centre-of-mass sums
+// differ in rounding (f64 prefix sums over the sorted bodies instead of the reference's sequential
+// f32 folds), which is why the host build stays the default and the strict path.
+//
+//   1. key[k]  = the body's orthant codes on levels 0..20 (3 bits each), computed with the
+//                reference's own recurrences: code bit i set iff p[i] > center[i]
+//                (shared.rs:245-254); child half width = hw/2, child centre = centre +- child half
+//                width (shared.rs:256-272).  Sorting by key puts the bodies in depth-first leaf order
+//                with children in orthant order.
+//   2. stable radix sort of (key, id) (rocPRIM).
+//   3. delta[k] = common levels of key[k], key[k+1]; body k opens the internal nodes of depths
+//                delta[k-1]+1 .. delta[k] (cells that contain k and k+1 but not k-1); its leaf sits at
+//                depth max(delta[k-1], delta[k]) + 1 -- the reference splits until a body is alone.
+//   4. an exclusive scan of (opened + 1) gives every node its pre-order index; an inclusive scan of
+//                {m, m x, m y, m z} in f64 gives every cell's mass and centre of mass by subtraction.
+//   5. emit: one thread per body writes its opened cells and its leaf.  A cell's last body is found
+//                by binary search on the sorted keys (all keys sharing its prefix), its skip link is
+//                the pre-order index after that body's leaf.
+// Bodies whose 63-bit keys collide need more than 21 levels: the build reports it and the caller
+// falls back to the host build (which goes to depth 192).
+#include "kernels.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace nbody {
+
+namespace {
+
+constexpr int kLevels = 21;
+
+struct Sum4 { double m, x, y, z; };
+struct Sum4Plus {
+    __host__ __device__ Sum4 operator()(const Sum4& a, const Sum4& b) const { return Sum4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
+};
+
+__global__ __launch_bounds__(256) void k_tree_keys(const float4* __restrict__ pos, const int* __restrict__ count,
+                                                   int n_upper, float cx0, float cy0, float cz0, float width,
+                                                   unsigned long long* __restrict__ keys, int* __restrict__ ids) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_upper) return;
+    if (k >= *count) {  // n_upper only bounds the live count: the unused tail sorts to the end (bit 63 set),
+        keys[k] = ~0ull;  // where every later kernel ignores it (they all read *count)
+        ids[k] = k;
+        return;
+    }
+    const float4 p = pos[k];
+    float cx = cx0, cy = cy0, cz = cz0;
+    float hw = width * 0.5f;  // Bounds::new
+    unsigned long long key = 0;
+#pragma unroll 1
+    for (int l = 0; l < kLevels; ++l) {
+        const bool bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // get_orthant
+        key = (key << 3) | (unsigned long long)((bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0));
+        hw = hw * 0.5f;                                            // create_orthant
+        cx = bx ? cx + hw : cx - hw;
+        cy = by ? cy + hw : cy - hw;
+        cz = bz ? cz + hw : cz - hw;
+    }
+    keys[k] = key;
+    ids[k] = k;
+}
+
+__device__ __forceinline__ int common_levels(unsigned long long a, unsigned long long b) {
+    const unsigned long long x = a ^ b;
+    if (x == 0) return kLevels;               // identical on all 21 levels
+    return (__clzll((long long)x) - 1) / 3;   // bit 63 is unused
+}
+
+// delta[k] for the boundary between sorted bodies k and k+1 (delta[n-1] = -1), opened[k], and the
+// per-body scan inputs
+__global__ __launch_bounds__(256) void k_tree_delta(const unsigned long long* __restrict__ keys,
+                                                    const int* __restrict__ ids, const float4* __restrict__ pos,
+                                                    const int* __restrict__ count, signed char* __restrict__ delta,
+                                                    int* __restrict__ emit_count, Sum4* __restrict__ sums,
+                                                    int* __restrict__ flags) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n = *count;
+    if (k >= n) return;
+    const unsigned long long key = keys[k];
+    const int d_next = (k + 1 < n) ? common_levels(key, keys[k + 1]) : -1;
+    const int d_prev = (k > 0) ? common_levels(keys[k - 1], key) : -1;
+    if (d_next >= kLevels) atomicOr(flags, 1);  // two bodies share all 21 levels: too deep for this build
+    delta[k] = (signed char)d_next;
+    emit_count[k] = max(0, d_next - d_prev) + 1;  // opened cells + the leaf
+    const float4 p = pos[ids[k]];
+    sums[k] = Sum4{double(p.w), double(p.w) * double(p.x), double(p.w) * double(p.y), double(p.w) * double(p.z)};
+}
+
+__global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __restrict__ keys,
+                                                   const int* __restrict__ ids, const float4* __restrict__ pos,
+                                                   const int* __restrict__ count, const signed char* __restrict__ delta,
+                                                   const int* __restrict__ base, const Sum4* __restrict__ incl,
+                                                   float width, float4* __restrict__ nodes, int node_cap,
+                                                   int* __restrict__ order, int* __restrict__ out_info) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n = *count;
+    if (n == 0) {  // the reference's empty root (barnes_hut.rs:145)
+        if (k == 0) {
+            if (node_cap >= 1) {
+                nodes[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                nodes[1] = make_float4(width * width, __int_as_float(1), width, __int_as_float(-1));
+            }
+            out_info[0] = 1;
+        }
+        return;
+    }
+    if (k >= n) return;
+    const int d_next = delta[k];
+    const int d_prev = (k > 0) ? delta[k - 1] : -1;
+    const int opened = max(0, d_next - d_prev);
+    const int first = base[k];
+    const int total = base[n - 1] + 1;  // the last sorted body opens no cell: only its leaf follows base[n-1]
+    if (k == 0) out_info[0] = total;
+    if (total > node_cap) { if (k == 0) atomicOr(out_info + 1, 2); return; }
+    const unsigned long long key = keys[k];
+    const Sum4 before = (k > 0) ? incl[k - 1] : Sum4{0.0, 0.0, 0.0, 0.0};
+    // cells this body opens, shallowest first
+    for (int t = 0; t < opened; ++t) {
+        const int d = d_prev + 1 + t;                   // depth of the cell: its bodies share d levels
+        const int shift = 3 * (kLevels - d);
+        const unsigned long long hi_key = key | ((shift >= 64) ? ~0ull : ((1ull << shift) - 1ull));
+        int lo = k, hi = n - 1;                          // last sorted body with key <= hi_key
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (keys[mid] <= hi_key) lo = mid; else hi = mid - 1;
+        }
+        const int j = lo;
+        const Sum4 upto = incl[j];
+        const double m = upto.m - before.m;
+        float w = width;
+        for (int q = 0; q < d; ++q) w = w * 0.5f;       // create_orthant halves the width exactly
+        const int skip = (j + 1 < n) ? base[j + 1] : total;
+        const int idx = first + t;
+        nodes[2 * idx] = make_float4(float((upto.x - before.x) / m), float((upto.y - before.y) / m),
+                                     float((upto.z - before.z) / m), float(m));
+        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(skip), w, __int_as_float(-1));
+    }
+    // the leaf
+    const int ld = max(d_prev, d_next) + 1;
+    float w = width;
+    for (int q = 0; q < ld; ++q) w = w * 0.5f;
+    const int id = ids[k];
+    const float4 p = pos[id];
+    const int idx = first + opened;
+    nodes[2 * idx] = p;
+    nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(idx + 1), w, __int_as_float(id));
+    order[k] = id;
+}
+
+// ancestors of the node-range split points (the walk's WalkSplit lists), root first.  Node t lies in
+// the run emitted by body k (base[k] <= t); its ancestors are the cells of depths 0 .. depth(t)-1 on
+// that body's path, each opened by the first sorted body that shares the prefix.
+__global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, const signed char* __restrict__ delta,
+                                 const int* __restrict__ base, int n, int n_nodes, int n_split,
+                                 int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc) {
+    const int s = blockIdx.x;
+    const int a = threadIdx.x;  // candidate ancestor depth
+    const int t = int((long long)n_nodes * s / n_split);
+    if (a == 0) {
+        first[s] = t;
+        if (s == n_split - 1) first[n_split] = n_nodes;
+    }
+    int lo = 0, hi = n - 1;    // body whose run contains node t: last k with base[k] <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (base[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int k = lo;
+    const int d_prev = (k > 0) ? delta[k - 1] : -1;
+    const int depth = d_prev + 1 + (t - base[k]);  // cells opened at k have depths d_prev+1.., the leaf follows
+    if (a == 0) n_anc[s] = min(depth, max_anc);
+    if (a >= depth || a >= max_anc) return;
+    const unsigned long long key = keys[k];
+    const int shift = 3 * (kLevels - a);
+    const unsigned long long lo_key = (shift >= 64) ? 0ull : (key >> shift) << shift;
+    int l2 = 0, h2 = k;        // first sorted body with key >= lo_key: it opened the depth-a cell
+    while (l2 < h2) {
+        const int mid = (l2 + h2) >> 1;
+        if (keys[mid] >= lo_key) h2 = mid; else l2 = mid + 1;
+    }
+    const int kf = l2;
+    const int dp = (kf > 0) ? delta[kf - 1] : -1;
+    anc[s * max_anc + a] = base[kf] + (a - (dp + 1));
+}
+
+}  // namespace
+
+size_t tree_build_workspace_bytes(size_t n_cap) {
+    size_t sort_bytes = 0, scan_i = 0, scan_s = 0;
+    unsigned long long* k = nullptr; int* v = nullptr; Sum4* s = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 63, 0);
+    (void)rocprim::exclusive_scan(nullptr, scan_i, v, v, 0, n_cap, rocprim::plus<int>(), 0);
+    (void)rocprim::inclusive_scan(nullptr, scan_s, s, s, n_cap, Sum4Plus(), 0);
+    const size_t tmp = std::max(sort_bytes, std::max(scan_i, scan_s));
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    return al(tmp) + 2 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
+}
+
+// Enqueues the whole build on `s`.  out_info (device, 2 ints): [0] = node count, [1] = flags
+// (1: deeper than 21 levels, 2: node_cap too small).  The caller reads it back before the walk.
+int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
+                        float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
+                        int* out_info, TreeDevWork* work) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    char* p = static_cast<char*>(workspace);
+    size_t sort_bytes = 0, scan_i = 0, scan_s = 0;
+    {
+        unsigned long long* k = nullptr; int* v = nullptr; Sum4* q = nullptr;
+        (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 63, 0);
+        (void)rocprim::exclusive_scan(nullptr, scan_i, v, v, 0, n_cap, rocprim::plus<int>(), 0);
+        (void)rocprim::inclusive_scan(nullptr, scan_s, q, q, n_cap, Sum4Plus(), 0);
+    }
+    size_t tmp_bytes = al(std::max(sort_bytes, std::max(scan_i, scan_s)));
+    void* tmp = p; p += tmp_bytes;
+    auto* keys_in = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
+    auto* keys = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
+    auto* ids_in = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    auto* ids = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    auto* emit_count = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    auto* base = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    auto* delta = reinterpret_cast<signed char*>(p); p += al(n_cap);
+    auto* sums = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
+    auto* incl = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
+    work->keys = keys; work->delta = delta; work->base = base;
+
+    (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s);
+    const int n = n_upper;
+    const dim3 grid(std::max(1, (n + 255) / 256)), block(256);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_tree_keys, grid, block, 0, s, pos, d_count, n, center[0], center[1], center[2], width, keys_in, ids_in);
+        size_t tb = tmp_bytes;
+        if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys, ids_in, ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_tree_delta, grid, block, 0, s, keys, ids, pos, d_count, delta, emit_count, sums, out_info + 1);
+        tb = tmp_bytes;
+        if (rocprim::exclusive_scan(tmp, tb, emit_count, base, 0, size_t(n), rocprim::plus<int>(), s) != hipSuccess) return -1;
+        tb = tmp_bytes;
+        if (rocprim::inclusive_scan(tmp, tb, sums, incl, size_t(n), Sum4Plus(), s) != hipSuccess) return -1;
+    }
+    hipLaunchKernelGGL(k_tree_emit, grid, block, 0, s, keys, ids, pos, d_count, delta, base, incl, width, nodes, node_cap,
+                       order, out_info);
+    return 0;
+}
+
+void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
+                           int* n_anc, int* anc, int max_anc) {
+    hipLaunchKernelGGL(k_tree_split_anc, dim3(n_split), dim3(32), 0, s, work.keys, work.delta, work.base, n, n_nodes,
+                       n_split, first, n_anc, anc, max_anc);
+}
+
+}  // namespace nbody

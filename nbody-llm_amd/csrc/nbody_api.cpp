@@ -62,6 +62,11 @@ struct NbodyHandle {
     float* h_pos = nullptr;    // pinned: all segments' positions
     int* h_counts = nullptr;   // pinned: all segments' counts
     std::vector<int32_t> own_order;
+    void* d_tree_ws = nullptr;   // device-build workspace (keys, sort buffers, scans)
+    size_t tree_ws_cap = 0;      // bodies it is sized for
+    int* d_tree_info = nullptr;  // [2] node count, flags
+    int* h_tree_info = nullptr;  // pinned
+    bool tree_on_device = false; // the last tree was built on the device (export copies it back)
     int* d_split = nullptr;      // [33 + 32 + 32*192] ints: first[], n_anc[], anc[][192]
     int* h_split = nullptr;      // pinned mirror
     float4* d_walk_planes = nullptr;
@@ -406,12 +411,21 @@ int ensure_tree_dev(NbodyHandle* h, size_t nodes, size_t order) {
 
 // BarnesHutSimulation::update_forces (barnes_hut.rs:250-263): rebuild the tree from the current
 // positions, then one walk per body.
+int bh_walk_device_tree(NbodyHandle* h, bool* fell_back);
+
 int bh_forces(NbodyHandle* h) {
     Shard& sh = h->sh;
     {
         int rc = exchange_wait(h);
         if (rc) return rc;
     }
+    if (h->cfg.tree_build == NBODY_TREE_DEVICE && sh.n_seg == 1) {
+        bool fell_back = false;
+        int rc = bh_walk_device_tree(h, &fell_back);
+        if (rc || !fell_back) return rc;
+        // deeper than 21 levels somewhere: this step's tree comes from the host build below
+    }
+    h->tree_on_device = false;
     auto t0 = clk::now();
     // positions of every segment (upper-bound counts) + the live counts, one sync
     for (int s = 0; s < sh.n_seg; ++s) {
@@ -513,6 +527,89 @@ int bh_forces(NbodyHandle* h) {
             td.split_n_anc = h->d_split + kMaxSplit + 1;
             td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
         }
+    }
+    {
+        ForceTimer t(h);
+        nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
+                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+// Barnes-Hut force pass with the octree built on the device (kernels_tree.hip): no positions go to
+// the host, no node array comes back; one 8-byte read-back (node count, flags) per step.
+int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
+    Shard& sh = h->sh;
+    auto t1 = clk::now();
+    const size_t n_cap = size_t(sh.seg_cap);
+    if (h->tree_ws_cap < n_cap) {
+        if (h->d_tree_ws) (void)hipFree(h->d_tree_ws);
+        h->d_tree_ws = nullptr; h->tree_ws_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_tree_ws, nbody::tree_build_workspace_bytes(n_cap)));
+        h->tree_ws_cap = n_cap;
+    }
+    if (!h->d_tree_info) {
+        HIP_TRY(h, hipMalloc(&h->d_tree_info, 2 * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(&h->h_tree_info, 2 * sizeof(int), hipHostMallocDefault));
+    }
+    // a Plummer sphere gives ~1.5 nodes per body; 4 per body + the count read-back below catch the rest
+    int rc = ensure_tree_dev(h, std::max<size_t>(h->d_node_cap, 4 * h->n_local + 64), h->n_local);
+    if (rc) return rc;
+    nbody::TreeDevWork work;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (nbody::build_octree_device(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->center, h->width,
+                                       h->d_tree_ws, n_cap, h->d_nodes, int(h->d_node_cap), h->d_order, h->d_tree_info,
+                                       &work) != 0)
+            return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(h->h_tree_info, h->d_tree_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (!(h->h_tree_info[1] & 2)) break;
+        rc = ensure_tree_dev(h, size_t(h->h_tree_info[0]) + 64, h->n_local);  // more nodes than allowed for: grow, rebuild
+        if (rc) return rc;
+    }
+    h->seg_count_host[0] = h->h_counts[0];
+    h->n_local = size_t(h->h_counts[0]);
+    h->count_dirty = false;
+    if (h->h_tree_info[1] & 1) { *fell_back = true; return NBODY_OK; }
+    const int n_nodes = h->h_tree_info[0];
+    const size_t n_order = h->n_local;
+    h->stats.tree_build_ms += ms_since(t1);
+    h->stats.tree_nodes = uint64_t(n_nodes);
+    h->tree_on_device = true;
+    h->tree.n_nodes = size_t(n_nodes);  // (the host copy is filled on demand by nbody_tree_export)
+
+    constexpr int kMaxSplit = 32, kMaxAnc = 192;
+    if (!h->d_split) {
+        HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
+    }
+    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((8192 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+    K = std::max(1, std::min(kMaxSplit, K));
+    while (K > 1 && K * 16 > n_nodes) K /= 2;
+    if (n_order == 0) K = 1;
+    nbody::TreeDev td;
+    td.nodes = h->d_nodes; td.n_nodes = n_nodes;
+    td.order = h->d_order; td.n_order = int(n_order);
+    td.n_split = K;
+    td.split_first = h->d_split;
+    td.split_n_anc = h->d_split + kMaxSplit + 1;
+    td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
+    if (n_order > 0)
+        nbody::launch_tree_split_anc(h->stream, work, int(n_order), n_nodes, K, h->d_split, h->d_split + kMaxSplit + 1,
+                                     h->d_split + kMaxSplit + 1 + kMaxSplit, kMaxAnc);
+    if (K > 1) {
+        const size_t need = size_t(K) * sh.seg_cap;
+        if (need > h->walk_planes_cap) {
+            if (h->d_walk_planes) (void)hipFree(h->d_walk_planes);
+            h->d_walk_planes = nullptr; h->walk_planes_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_walk_planes, need * sizeof(float4)));
+            h->walk_planes_cap = need;
+        }
+        td.split_planes = h->d_walk_planes;
+        td.split_stride = size_t(sh.seg_cap);
     }
     {
         ForceTimer t(h);
@@ -639,9 +736,9 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
+                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_tree_ws, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split};
+    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -653,6 +750,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (cfg->method != NBODY_BRUTE_FORCE && cfg->method != NBODY_BARNES_HUT) return fail(nullptr, NBODY_ERR_INVALID, "unknown method");
     if (cfg->math_mode != NBODY_MATH_STRICT && cfg->math_mode != NBODY_MATH_FAST) return fail(nullptr, NBODY_ERR_INVALID, "unknown math_mode");
     if (cfg->leaf_mode != NBODY_LEAF_REFERENCE) return fail(nullptr, NBODY_ERR_INVALID, "unknown leaf_mode");
+    if (cfg->tree_build != NBODY_TREE_HOST && cfg->tree_build != NBODY_TREE_DEVICE) return fail(nullptr, NBODY_ERR_INVALID, "unknown tree_build");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, NBODY_ERR_INVALID, "bad rank/world_size");
     if (cfg->capacity == 0 || cfg->capacity > (1ull << 30)) return fail(nullptr, NBODY_ERR_INVALID, "capacity must be in [1, 2^30]");
 
@@ -1029,6 +1127,13 @@ int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* sk
     const size_t n = h->tree.n_nodes;
     if (n_nodes) *n_nodes = n;
     if (!com_mass && !width && !skip) return NBODY_OK;
+    if (h->tree_on_device) {  // the octree lives on the device only: fetch it
+        int rc = use_device(h);
+        if (rc) return rc;
+        h->tree.reserve(n, 0);
+        HIP_TRY(h, hipMemcpyAsync(h->tree.nodes, h->d_nodes, n * sizeof(nbody::NodeRec), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "tree export buffer too small");
     for (size_t i = 0; i < n; ++i) {
         const nbody::NodeRec& r = h->tree.nodes[i];

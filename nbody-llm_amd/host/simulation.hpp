@@ -86,7 +86,7 @@ public:
 
 protected:
     Simulation(int method, const std::vector<PointParticle>& points, const Bounds& bounds, int math_mode,
-               size_t capacity, int host_threads) : bounds_(bounds) {
+               size_t capacity, int host_threads, int tree_build = NBODY_TREE_HOST) : bounds_(bounds) {
         NbodyConfig cfg{};
         cfg.struct_size = sizeof(cfg);
         cfg.method = method;
@@ -97,6 +97,7 @@ protected:
         cfg.world_size = 1;
         cfg.host_threads = host_threads;
         cfg.capacity = capacity ? capacity : (points.empty() ? 1 : points.size());
+        cfg.tree_build = tree_build;
         int rc = nbody_create(&cfg, &h_);
         if (rc) throw Error(rc, nbody_last_error(nullptr));
         check(nbody_set_bounds(h_, bounds.center.data(), bounds.width));
@@ -141,8 +142,9 @@ private:
 class BarnesHutSimulation : public Simulation {
 public:
     BarnesHutSimulation(const std::vector<PointParticle>& points, const Bounds& bounds,
-                        int math_mode = NBODY_MATH_FAST, size_t capacity = 0, int host_threads = 0)
-        : Simulation(NBODY_BARNES_HUT, points, bounds, math_mode, capacity, host_threads) {}
+                        int math_mode = NBODY_MATH_FAST, size_t capacity = 0, int host_threads = 0,
+                        int tree_build = NBODY_TREE_HOST)
+        : Simulation(NBODY_BARNES_HUT, points, bounds, math_mode, capacity, host_threads, tree_build) {}
     std::unique_ptr<BarnesHutSimulation> clone() const {
         return std::unique_ptr<BarnesHutSimulation>(new BarnesHutSimulation(clone_handle(), *this));
     }

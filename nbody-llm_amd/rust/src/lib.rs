@@ -26,6 +26,8 @@ struct NbodyConfig {
     world_size: i32,
     host_threads: i32,
     capacity: u64,
+    tree_build: i32,
+    reserved: i32,
 }
 
 #[repr(C)]
@@ -99,6 +101,8 @@ impl<const METHOD: i32> HipSimulation<METHOD> {
             world_size: 1,
             host_threads: 0,
             capacity: (points.len().max(1) * 2) as u64, // headroom for add_point
+            tree_build: 0,
+            reserved: 0,
         };
         let mut h: *mut NbodyHandle = std::ptr::null_mut();
         let rc = unsafe { nbody_create(&cfg, &mut h) };

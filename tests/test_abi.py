@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol(nb):
 
 
 def test_struct_layouts_match_the_header(nb):
-    # uint32 + 7 x int32 + uint64; 6 x uint64 + 4 x double
-    assert ctypes.sizeof(nb.NbodyConfig) == 40
+    # uint32 + 7 x int32 + uint64 + 2 x int32; 6 x uint64 + 4 x double
+    assert ctypes.sizeof(nb.NbodyConfig) == 48
     assert ctypes.sizeof(nb.NbodyStats) == 80
     assert nb.PARTICLE_DTYPE.itemsize == 40
     assert [nb.PARTICLE_DTYPE.fields[k][1] for k in ("position", "velocity", "acceleration", "mass")] == [0, 12, 24, 36]
@@ -47,11 +47,11 @@ def test_no_device_means_loud_failure(nb):
 
 def test_create_rejects_bad_configs(nb):
     h = ctypes.c_void_p()
-    cfg = nb.NbodyConfig(ctypes.sizeof(nb.NbodyConfig), 7, 0, 0, -1, 0, 1, 0, 16)
+    cfg = nb.NbodyConfig(ctypes.sizeof(nb.NbodyConfig), 7, 0, 0, -1, 0, 1, 0, 16, 0, 0)
     assert nb.lib.nbody_create(ctypes.byref(cfg), ctypes.byref(h)) == nb.NBODY_ERR_INVALID
-    cfg = nb.NbodyConfig(3, 0, 0, 0, -1, 0, 1, 0, 16)
+    cfg = nb.NbodyConfig(3, 0, 0, 0, -1, 0, 1, 0, 16, 0, 0)
     assert nb.lib.nbody_create(ctypes.byref(cfg), ctypes.byref(h)) == nb.NBODY_ERR_INVALID
-    cfg = nb.NbodyConfig(ctypes.sizeof(nb.NbodyConfig), 0, 0, 0, -1, 2, 2, 0, 16)
+    cfg = nb.NbodyConfig(ctypes.sizeof(nb.NbodyConfig), 0, 0, 0, -1, 2, 2, 0, 16, 0, 0)
     assert nb.lib.nbody_create(ctypes.byref(cfg), ctypes.byref(h)) == nb.NBODY_ERR_INVALID
     assert nb.lib.nbody_step_by(None, 0.1) == nb.NBODY_ERR_INVALID
 

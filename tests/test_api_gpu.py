@@ -50,7 +50,7 @@ def test_reupload_replaces_the_body_vector(gpu, orc):
 def test_step_without_bounds_is_an_error(gpu):
     nb = gpu
     h = C.c_void_p()
-    cfg = nb.NbodyConfig(C.sizeof(nb.NbodyConfig), nb.BRUTE_FORCE, nb.STRICT, 0, -1, 0, 1, 0, 16)
+    cfg = nb.NbodyConfig(C.sizeof(nb.NbodyConfig), nb.BRUTE_FORCE, nb.STRICT, 0, -1, 0, 1, 0, 16, 0, 0)
     assert nb.lib.nbody_create(C.byref(cfg), C.byref(h)) == 0
     try:
         assert nb.lib.nbody_step_by(h, 1e-3) == nb.NBODY_ERR_INVALID
@@ -65,7 +65,7 @@ def test_step_without_bounds_is_an_error(gpu):
 def test_device_ordinal_out_of_range(gpu):
     nb = gpu
     h = C.c_void_p()
-    cfg = nb.NbodyConfig(C.sizeof(nb.NbodyConfig), 0, 0, 0, 99, 0, 1, 0, 16)
+    cfg = nb.NbodyConfig(C.sizeof(nb.NbodyConfig), 0, 0, 0, 99, 0, 1, 0, 16, 0, 0)
     assert nb.lib.nbody_create(C.byref(cfg), C.byref(h)) == nb.NBODY_ERR_INVALID
     assert b"out of range" in nb.lib.nbody_last_error(None)
 

@@ -1,0 +1,130 @@
+"""Device-side octree build (NBODY_TREE_DEVICE) against the oracle.
+Index work is exact: the same cells in the same pre-order with the same skip links, widths and
+leaf bodies as barnes_hut.rs:143-183.  The centre-of-mass sums are f64 prefix sums instead of the
+reference's sequential f32 folds: com/mass agree to the rounding of the reference's own fold (n * 2^-24),
+so an opening test that sits on the edge can flip: node counts within 1e-3, accelerations <= 1e-5 for
+the equal-mass-ish Plummer sets (the disc's 1 : 3e-5 mass ratio makes the reference's f32 root mass
+itself 2e-4 off the exact sum)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BOX = ((0.0, 0.0, 0.0), 64.0)
+
+
+def build_and_compare(nb, orc, ics, box, sd, math_mode):
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, box[0], box[1], threads=8)
+    rt = orc.bh_build_tree(ics.astype(orc.P32), box[0], box[1])
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=math_mode, tree_build=nb.TREE_DEVICE) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+        t = sim.tree()
+    assert len(t["skip"]) == len(rt["skip"]) == s.tree_nodes
+    assert np.array_equal(t["skip"], rt["skip"]), "skip links differ"
+    assert np.array_equal(t["width"], rt["width"]), "cell widths differ"
+    leaves = rt["nchild"] == 0
+    assert np.array_equal(t["com_mass"][leaves].view(np.uint32), rt["com_mass"][leaves].view(np.uint32)), "leaves are copies of the bodies"
+    # a sequential f32 fold over n terms (the reference) carries up to ~n * 2^-24 of rounding; the f64
+    # prefix sums are exact to f32: the bound on the difference is the reference's own error
+    tol = max(2e-6, len(ics) * 6e-8)
+    scale = box[1]
+    assert np.abs(t["com_mass"][:, :3].astype(np.float64) - rt["com_mass"][:, :3]).max() < tol * scale
+    assert np.allclose(t["com_mass"][:, 3], rt["com_mass"][:, 3], rtol=tol, atol=0)
+    return got, ref, s, (acc_n, vis_n)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 9, 300, 1024, 5000, 20000])
+@pytest.mark.parametrize("theta2", [0.25, 1.0])
+def test_device_tree_structure_and_forces(gpu, orc, n, theta2):
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.02, dt=1e-3, theta2=theta2)
+    ics = nb.plummer(n, seed=40 + n)
+    ics["mass"] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
+    got, ref, s, (acc_n, vis_n) = build_and_compare(nb, orc, ics, BOX, sd, nb.STRICT)
+    assert abs(int(s.interactions) - acc_n) <= max(2, 1e-3 * acc_n)
+    assert abs(int(s.node_visits) - vis_n) <= max(2, 1e-3 * vis_n)
+    if np.abs(ref["acceleration"]).max() > 0:
+        assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+
+
+def test_device_tree_reference_workload_and_offcentre_box(gpu, orc):
+    """The reference's disc in its width-10 box, and a box whose centre arithmetic rounds."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.02, dt=3e-2, theta2=1.0)
+    ics = nb.disc(6000, seed=4)
+    build_and_compare(nb, orc, ics, ((0.0, 0.0, 0.0), 10.0), sd, nb.FAST)
+    build_and_compare(nb, orc, ics, ((0.1, -0.3, 0.7), 13.7), sd, nb.FAST)
+
+
+def test_device_tree_steps_track_the_oracle(gpu, orc):
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(4000, seed=7)
+    ref = ics.copy().astype(orc.P32)
+    tot = 0
+    for _ in range(10):
+        ref, a, _ = orc.bh_step_by(ref, sd, BOX[0], BOX[1], sd["dt"], threads=4)
+        tot += a
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.init()
+        sim.steps(10)
+        got = sim.get_points()
+        s = sim.stats()
+    assert abs(int(s.interactions) - tot) <= 1e-3 * tot
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
+    assert rel_err(got["velocity"], ref["velocity"]) < 1e-5
+
+
+def test_device_tree_with_escapes(gpu, orc):
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 2.0)
+    sd = dict(g=1.0, g_soft=0.05, dt=2e-2, theta2=0.5)
+    ics = nb.plummer(3000, seed=9)
+    ref = ics.copy().astype(orc.P32)
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as sim:
+        sim.settings = nb.Settings(**sd)
+        for _ in range(8):
+            sim.step()
+            ref, _, _ = orc.bh_step_by(ref, sd, box[0], box[1], sd["dt"], threads=2)
+            assert len(sim) == len(ref)
+        got = sim.get_points()
+    assert len(ref) < 2800 and np.array_equal(got["mass"], ref["mass"])
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-5
+
+
+def test_deeper_than_21_levels_falls_back_to_the_host_build(gpu, orc):
+    """Two bodies 1e-7 apart in a width-64 box separate only below level 21: the device build reports
+    it and the step uses the host build (exact counts again); coincident bodies still raise."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(500, seed=3)
+    ics["position"][7] = ics["position"][3] + np.float32(2e-7)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=2)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT, tree_build=nb.TREE_DEVICE) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        s = sim.stats()
+        got = sim.get_points()
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    ics["position"][7] = ics["position"][3]
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, tree_build=nb.TREE_DEVICE) as sim:
+        with pytest.raises(nb.NbodyError) as e:
+            sim.update_forces()
+        assert e.value.code == nb.NBODY_ERR_TREE_DEPTH
+
+
+def test_device_tree_full_size_65536(gpu, orc):
+    nb = gpu
+    sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(65536)
+    got, ref, s, (acc_n, vis_n) = build_and_compare(nb, orc, ics, BOX, sd, nb.FAST)
+    assert abs(int(s.interactions) - acc_n) <= 1e-3 * acc_n
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
