@@ -49,7 +49,7 @@ __device__ __forceinline__ void sym_rest_block(const float4* __restrict__ pos, i
 // CU: the dispatcher then has no choice but to spread the grid evenly.  With small workgroups it
 // packs some CUs to their register limit and leaves others nearly empty, and the kernel lasts as
 // long as the fullest SIMD (measured with in-kernel stamps: wave lifetimes 560-960 us, +55 %).
-template <int IPT, int WPB, int DBG = 0>
+template <int IPT, int WPB, int DBG = 0, bool PK = false>
 __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ pos, const int* __restrict__ count,
                                                      int A, int K, const int* __restrict__ bounds, int sym_sets,
                                                      float4* __restrict__ planes, size_t plane_stride, float eps2,
@@ -106,9 +106,20 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
     unsigned long long t_beg = 0, r_beg = 0;
     if (DBG & 4) { t_beg = __builtin_amdgcn_s_memtime(); r_beg = __builtin_amdgcn_s_memrealtime(); }
     float4 nxt = (k0 < k1) ? load_chunk(k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // packed form (PK): the resident bodies two per register pair, see bf_pair.h
+    v2f xi2[IPT / 2], yi2[IPT / 2], zi2[IPT / 2], mi2[IPT / 2], axi2[IPT / 2], ayi2[IPT / 2], azi2[IPT / 2];
+    if (PK) {
+#pragma unroll
+        for (int q = 0; q < IPT / 2; ++q) {
+            xi2[q] = v2f{xi[2 * q], xi[2 * q + 1]}; yi2[q] = v2f{yi[2 * q], yi[2 * q + 1]};
+            zi2[q] = v2f{zi[2 * q], zi[2 * q + 1]}; mi2[q] = v2f{mi[2 * q], mi[2 * q + 1]};
+            axi2[q] = ayi2[q] = azi2[q] = v2f{0.f, 0.f};
+        }
+    }
     for (int k = k0; k < k1; ++k) {
         float xj = nxt.x, yj = nxt.y, zj = nxt.z, mj = nxt.w;
         float axj = 0.f, ayj = 0.f, azj = 0.f;
+        v2f axj2 = {0.f, 0.f}, ayj2 = {0.f, 0.f}, azj2 = {0.f, 0.f};
         if (k + 1 < k1) nxt = load_chunk(k + 1);
         // The SIMD arbitrates VALU issue by priority, then age: at equal priority the oldest wave
         // runs at full speed, the youngest gets the leftovers, and once the old waves are done the
@@ -126,14 +137,29 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
 #pragma unroll 2
         for (int s = 0; s < 64; ++s) {
             const float x2 = rotl(xj, src_lane2), y2 = rotl(yj, src_lane2), z2 = rotl(zj, src_lane2), m2 = rotl(mj, src_lane2);
-            pair_evals<IPT, DBG>(xi, yi, zi, mi, axi, ayi, azi, xj, yj, zj, mj, axj, ayj, azj, eps2v);
-            // the accumulators follow their body; they are next needed at the END of the next step
-            axj = rotl(axj, src_lane); ayj = rotl(ayj, src_lane); azj = rotl(azj, src_lane);
+            if (PK) {
+                pair_evals_pk<IPT / 2, DBG>(xi2, yi2, zi2, mi2, axi2, ayi2, azi2, xj, yj, zj, mj, axj2, ayj2, azj2, eps2v);
+                axj2.x = rotl(axj2.x, src_lane); ayj2.x = rotl(ayj2.x, src_lane); azj2.x = rotl(azj2.x, src_lane);
+                axj2.y = rotl(axj2.y, src_lane); ayj2.y = rotl(ayj2.y, src_lane); azj2.y = rotl(azj2.y, src_lane);
+            } else {
+                pair_evals<IPT, DBG>(xi, yi, zi, mi, axi, ayi, azi, xj, yj, zj, mj, axj, ayj, azj, eps2v);
+                // the accumulators follow their body; they are next needed at the END of the next step
+                axj = rotl(axj, src_lane); ayj = rotl(ayj, src_lane); azj = rotl(azj, src_lane);
+            }
             xj = x1; yj = y1; zj = z1; mj = m1;
             x1 = x2; y1 = y2; z1 = z2; m1 = m2;
         }
+        if (PK) { axj = axj2.x + axj2.y; ayj = ayj2.x + ayj2.y; azj = azj2.x + azj2.y; }
         const int d = k / IPT + 1;  // set distance 1..sym_sets
         planes[size_t(d - 1) * plane_stride + size_t(chunk_of(k)) * 64 + lane] = make_float4(axj, ayj, azj, 0.f);
+    }
+    if (PK) {
+#pragma unroll
+        for (int q = 0; q < IPT / 2; ++q) {
+            axi[2 * q] = axi2[q].x; axi[2 * q + 1] = axi2[q].y;
+            ayi[2 * q] = ayi2[q].x; ayi[2 * q + 1] = ayi2[q].y;
+            azi[2 * q] = azi2[q].x; azi[2 * q + 1] = azi2[q].y;
+        }
     }
 
     if (DBG & 4) {  // diagnostic build: shader cycles and 100 MHz ticks of this wave's chunk loop, into a
@@ -355,6 +381,7 @@ extern "C" int nbody_sym_read_stamps(unsigned long long* out, int n_waves) { ret
 extern "C" int nbody_sym_wpb = 12;     // waves per workgroup: 16, 12 or 8   (tuning hooks, tools/tune_sym.py)
 extern "C" int nbody_sym_rounds = 1;   // rounds of workgroups per CU
 extern "C" int nbody_sym_debug = 0;    // 4: diagnostic build with in-kernel cycle stamps
+extern "C" int nbody_sym_packed = 1;   // 1: packed-fp32 pair evaluation (pair_evals_pk), 0: scalar; env NBODY_SYM_PACKED
 namespace nbody {
 
 // ----------------------------------------------------------------------------------- host side
@@ -418,14 +445,24 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
     const int main_blocks = (p.A * p.K + p.wpb - 1) / p.wpb;
     const int rest_blocks = int(p.n_pad / 64);  // one workgroup per 64 bodies
     const dim3 grid(main_blocks + rest_blocks), block(p.wpb * 64);
-#define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.plane_stride, g_soft2, p.res_combine)
-    if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
-        if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
-    } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
-    } else if (nbody_sym_debug == 6) { SYM_LAUNCH(16, 6);
-    } else if (nbody_sym_debug == 7) { SYM_LAUNCH(16, 7);
+#define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG, PKV>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.plane_stride, g_soft2, p.res_combine)
+    if (nbody_sym_packed) {
+        constexpr bool PKV = true;
+        if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
+            if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
+        } else {
+            if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
+        }
     } else {
-        if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
+        constexpr bool PKV = false;
+        if (nbody_sym_debug == 4) {
+            if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
+        } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
+        } else if (nbody_sym_debug == 6) { SYM_LAUNCH(16, 6);
+        } else if (nbody_sym_debug == 7) { SYM_LAUNCH(16, 7);
+        } else {
+            if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
+        }
     }
 #undef SYM_LAUNCH
 }

@@ -50,6 +50,30 @@ __global__ __launch_bounds__(256) void k(float* out, float b, float c, unsigned 
                 "v_pk_mul_f32 %3, %3, %3\n v_pk_mul_f32 %3, %3, %9\n v_pk_mul_f32 %3, %3, %3\n"
                 "v_pk_fma_f32 %0, %0, %3, %0\n v_pk_fma_f32 %1, %1, %3, %1\n v_pk_fma_f32 %2, %2, %3, %2\n"
                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(a4), "+v"(a5), "+v"(p6), "+v"(p7) : "v"(bb), "v"(cc));
+        } else if (KIND == 6) {  // 8 independent v_fmac_f32 in the 4-byte VOP2 encoding
+            asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n"
+                         "v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+        } else if (KIND == 7) {  // the same in the 8-byte VOP3 encoding
+            asm volatile("v_fmac_f32_e64 %0, %8, %9\n v_fmac_f32_e64 %1, %8, %9\n v_fmac_f32_e64 %2, %8, %9\n v_fmac_f32_e64 %3, %8, %9\n"
+                         "v_fmac_f32_e64 %4, %8, %9\n v_fmac_f32_e64 %5, %8, %9\n v_fmac_f32_e64 %6, %8, %9\n v_fmac_f32_e64 %7, %8, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+        } else if (KIND == 8) {  // 8 independent v_mul_f32 (VOP2)
+            asm volatile("v_mul_f32_e32 %0, %8, %0\n v_mul_f32_e32 %1, %8, %1\n v_mul_f32_e32 %2, %8, %2\n v_mul_f32_e32 %3, %8, %3\n"
+                         "v_mul_f32_e32 %4, %8, %4\n v_mul_f32_e32 %5, %8, %5\n v_mul_f32_e32 %6, %8, %6\n v_mul_f32_e32 %7, %8, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+        } else if (KIND == 9) {  // v_fma_f32 with the accumulator as src2 (what fma(-x, s, acc) compiles to)
+            asm volatile("v_fma_f32 %0, -%8, %9, %0\n v_fma_f32 %1, -%8, %9, %1\n v_fma_f32 %2, -%8, %9, %2\n v_fma_f32 %3, -%8, %9, %3\n"
+                         "v_fma_f32 %4, -%8, %9, %4\n v_fma_f32 %5, -%8, %9, %5\n v_fma_f32 %6, -%8, %9, %6\n v_fma_f32 %7, -%8, %9, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+        } else if (KIND == 10) {  // v_fma_f32 d, x, x, c (the r2 start)
+            asm volatile("v_fma_f32 %0, %1, %1, %9\n v_fma_f32 %1, %2, %2, %9\n v_fma_f32 %2, %3, %3, %9\n v_fma_f32 %3, %4, %4, %9\n"
+                         "v_fma_f32 %4, %5, %5, %9\n v_fma_f32 %5, %6, %6, %9\n v_fma_f32 %6, %7, %7, %9\n v_fma_f32 %7, %0, %0, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+        } else if (KIND == 11) {  // v_fma_f32 with three different varying sources
+            asm volatile("v_fma_f32 %0, %1, %2, %3\n v_fma_f32 %1, %2, %3, %4\n v_fma_f32 %2, %3, %4, %5\n v_fma_f32 %3, %4, %5, %6\n"
+                         "v_fma_f32 %4, %5, %6, %7\n v_fma_f32 %5, %6, %7, %0\n v_fma_f32 %6, %7, %0, %1\n v_fma_f32 %7, %0, %1, %2\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
         } else if (KIND == 5) {  // 4 fma + 1 rsq interleaved (does the transcendental co-issue?)
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_rsq_f32 %4, %4\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                          "v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_rsq_f32 %7, %7\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n"
@@ -87,8 +111,14 @@ int main() {
     float* out; unsigned long long* clk;
     CHECK(hipMalloc(&out, sizeof(float) * 256 * 8 * 256));
     CHECK(hipMalloc(&clk, 16));
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {3, 8}) {
         if (run<0>("v_fma_f32", 8, w, out, clk)) return 1;
+        if (run<6>("v_fmac_f32 VOP2 (4 B)", 8, w, out, clk)) return 1;
+        if (run<7>("v_fmac_f32 VOP3 (8 B)", 8, w, out, clk)) return 1;
+        if (run<8>("v_mul_f32 VOP2 (4 B)", 8, w, out, clk)) return 1;
+        if (run<9>("v_fma_f32 d,-b,c,d", 8, w, out, clk)) return 1;
+        if (run<10>("v_fma_f32 d,x,x,c", 8, w, out, clk)) return 1;
+        if (run<11>("v_fma_f32 d,x,y,z", 8, w, out, clk)) return 1;
         if (run<1>("v_pk_fma_f32", 8, w, out, clk)) return 1;
         if (run<2>("v_rsq_f32", 8, w, out, clk)) return 1;
         if (run<5>("4 fma : 1 rsq mix (10 instr)", 10, w, out, clk)) return 1;

@@ -9,13 +9,14 @@ var = ctypes.c_int.in_dll(nb.lib, "nbody_bf_fast_variant")
 wpb = ctypes.c_int.in_dll(nb.lib, "nbody_sym_wpb")
 rounds = ctypes.c_int.in_dll(nb.lib, "nbody_sym_rounds")
 dbg = ctypes.c_int.in_dll(nb.lib, "nbody_sym_debug")
+pk = ctypes.c_int.in_dll(nb.lib, "nbody_sym_packed")
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST)
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
-cases = [("sym", 0, w, r) for w, r in ((16, 1), (16, 2), (12, 1), (12, 2), (12, 3), (8, 2), (8, 3))]
+cases = [("sym", 0, w, r, p) for p in (0, 1) for w, r in ((16, 1), (16, 2), (12, 1), (12, 2), (8, 2), (8, 3))]
 res = {c: [] for c in cases}
 for rnd in range(3):
     for c in cases:
-        var.value, wpb.value, rounds.value, dbg.value = c[1], c[2], c[3], 0
+        var.value, wpb.value, rounds.value, dbg.value, pk.value = c[1], c[2], c[3], 0, c[4]
         sim.update_forces(); sim.sync()
         sim.set_profiling(True); sim.reset_stats()
         import time
@@ -28,3 +29,12 @@ for rnd in range(3):
 for c in cases:
     r = sorted(res[c], key=lambda x: x[1])
     print(f"{c}: dominant kernel {min(x[0] for x in r):.4f} ms; whole force pass (3 kernels, wall) min {r[0][1]:.4f} median {r[len(r)//2][1]:.4f} ms -> {n*(n-1)/r[0][1]/1e9:.2f} T interactions/s")
+
+import numpy as np
+accs = []
+for p in (0, 1):
+    var.value, wpb.value, rounds.value, dbg.value, pk.value = 0, 12, 1, 0, p
+    sim.update_forces(); sim.sync()
+    accs.append(np.array(sim.get_points()["acceleration"], dtype=np.float64))
+scale = np.abs(accs[0]).max()
+print(f"packed vs unpacked: max |diff| / max |acc| = {np.abs(accs[0] - accs[1]).max() / scale:.3e}")
