@@ -97,7 +97,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float v) { v2f r = {v, v}; return r; }
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int IPT2, int DBG = 0>
+template <int IPT2, int DBG = 0, bool SYM = true>
 __device__ __forceinline__ void pair_evals_pk(const v2f (&xi)[IPT2], const v2f (&yi)[IPT2], const v2f (&zi)[IPT2],
                                               const v2f (&mi)[IPT2], v2f (&axi)[IPT2], v2f (&ayi)[IPT2],
                                               v2f (&azi)[IPT2], float xj, float yj, float zj, float mj, v2f& axj,
@@ -135,19 +135,43 @@ __device__ __forceinline__ void pair_evals_pk(const v2f (&xi)[IPT2], const v2f (
 #pragma unroll
     for (int q = 0; q < IPT2; ++q) sj[q] = mj2 * r[q];    // what body j does to bodies i
     __builtin_amdgcn_sched_barrier(0);
+    if (SYM) {
 #pragma unroll
-    for (int q = 0; q < IPT2; ++q) r[q] = mi[q] * r[q];   // what bodies i do to body j
-    __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < IPT2; ++q) r[q] = mi[q] * r[q];   // what bodies i do to body j
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < IPT2; ++q) {
-        axi[q] = pk_fma(dx[q], sj[q], axi[q]);
-        axj = pk_fma(-dx[q], r[q], axj);
-        ayi[q] = pk_fma(dy[q], sj[q], ayi[q]);
-        ayj = pk_fma(-dy[q], r[q], ayj);
-        azi[q] = pk_fma(dz[q], sj[q], azi[q]);
-        azj = pk_fma(-dz[q], r[q], azj);
+        for (int q = 0; q < IPT2; ++q) {
+            axi[q] = pk_fma(dx[q], sj[q], axi[q]);
+            axj = pk_fma(-dx[q], r[q], axj);
+            ayi[q] = pk_fma(dy[q], sj[q], ayi[q]);
+            ayj = pk_fma(-dy[q], r[q], ayj);
+            azi[q] = pk_fma(dz[q], sj[q], azi[q]);
+            azj = pk_fma(-dz[q], r[q], azj);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {  // one-sided: only the resident bodies are updated
+#pragma unroll
+        for (int q = 0; q < IPT2; ++q) axi[q] = pk_fma(dx[q], sj[q], axi[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < IPT2; ++q) ayi[q] = pk_fma(dy[q], sj[q], ayi[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < IPT2; ++q) azi[q] = pk_fma(dz[q], sj[q], azi[q]);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// scalar register arrays <-> packed pairs (bodies 2q and 2q+1 share a register pair)
+template <int IPT>
+__device__ __forceinline__ void pack_pairs(const float (&a)[IPT], v2f (&b)[IPT / 2]) {
+#pragma unroll
+    for (int q = 0; q < IPT / 2; ++q) b[q] = v2f{a[2 * q], a[2 * q + 1]};
+}
+template <int IPT>
+__device__ __forceinline__ void unpack_pairs(const v2f (&b)[IPT / 2], float (&a)[IPT]) {
+#pragma unroll
+    for (int q = 0; q < IPT / 2; ++q) { a[2 * q] = b[q].x; a[2 * q + 1] = b[q].y; }
 }
 
 }  // namespace

@@ -109,12 +109,8 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
     // packed form (PK): the resident bodies two per register pair, see bf_pair.h
     v2f xi2[IPT / 2], yi2[IPT / 2], zi2[IPT / 2], mi2[IPT / 2], axi2[IPT / 2], ayi2[IPT / 2], azi2[IPT / 2];
     if (PK) {
-#pragma unroll
-        for (int q = 0; q < IPT / 2; ++q) {
-            xi2[q] = v2f{xi[2 * q], xi[2 * q + 1]}; yi2[q] = v2f{yi[2 * q], yi[2 * q + 1]};
-            zi2[q] = v2f{zi[2 * q], zi[2 * q + 1]}; mi2[q] = v2f{mi[2 * q], mi[2 * q + 1]};
-            axi2[q] = ayi2[q] = azi2[q] = v2f{0.f, 0.f};
-        }
+        pack_pairs<IPT>(xi, xi2); pack_pairs<IPT>(yi, yi2); pack_pairs<IPT>(zi, zi2); pack_pairs<IPT>(mi, mi2);
+        pack_pairs<IPT>(axi, axi2); pack_pairs<IPT>(ayi, ayi2); pack_pairs<IPT>(azi, azi2);
     }
     for (int k = k0; k < k1; ++k) {
         float xj = nxt.x, yj = nxt.y, zj = nxt.z, mj = nxt.w;
@@ -153,14 +149,7 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
         const int d = k / IPT + 1;  // set distance 1..sym_sets
         planes[size_t(d - 1) * plane_stride + size_t(chunk_of(k)) * 64 + lane] = make_float4(axj, ayj, azj, 0.f);
     }
-    if (PK) {
-#pragma unroll
-        for (int q = 0; q < IPT / 2; ++q) {
-            axi[2 * q] = axi2[q].x; axi[2 * q + 1] = axi2[q].y;
-            ayi[2 * q] = ayi2[q].x; ayi[2 * q + 1] = ayi2[q].y;
-            azi[2 * q] = azi2[q].x; azi[2 * q + 1] = azi2[q].y;
-        }
-    }
+    if (PK) { unpack_pairs<IPT>(axi2, axi); unpack_pairs<IPT>(ayi2, ayi); unpack_pairs<IPT>(azi2, azi); }
 
     if (DBG & 4) {  // diagnostic build: shader cycles and 100 MHz ticks of this wave's chunk loop, into a
                     // buffer of their own that nothing else reads
@@ -214,7 +203,7 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
 // as wave-uniform broadcasts (ds_read_b128), 12 VALU + 1 v_rsq_f32 per interaction.  Slices are cut
 // to the body (not to the chunk), so all waves carry the same number of partners.  Output: one
 // resident-side plane per slice (added by k_bf_sym_reduce with the others).
-template <int IPT, int WPB>
+template <int IPT, int WPB, bool PK>
 __global__ __launch_bounds__(WPB * 64) void k_bf_os(const float4* __restrict__ pos_all,
                                                     const int* __restrict__ seg_count, int n_seg, int seg_cap,
                                                     int my_seg, int A, int K, float4* __restrict__ planes,
@@ -244,6 +233,12 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_os(const float4* __restrict__ p
     const long long r0 = R * part / K, r1 = R * (part + 1) / K;
     long long seg_first = 0;  // remote index of the current segment's first body
     float dummy_x = 0.f, dummy_y = 0.f, dummy_z = 0.f;  // pair_evals' travelling-side accumulators (unused)
+    v2f dummy2 = {0.f, 0.f};
+    v2f xi2[IPT / 2], yi2[IPT / 2], zi2[IPT / 2], mi2[IPT / 2], axi2[IPT / 2], ayi2[IPT / 2], azi2[IPT / 2];
+    if (PK) {
+        pack_pairs<IPT>(xi, xi2); pack_pairs<IPT>(yi, yi2); pack_pairs<IPT>(zi, zi2); pack_pairs<IPT>(mi, mi2);
+        pack_pairs<IPT>(axi, axi2); pack_pairs<IPT>(ayi, ayi2); pack_pairs<IPT>(azi, azi2);
+    }
     for (int s = 0; s < n_seg; ++s) {
         if (s == my_seg) continue;
         const int ns = seg_count[s];
@@ -270,8 +265,12 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_os(const float4* __restrict__ p
             float4 pj = stage[wslot][buf][0];  // wave-uniform address: LDS broadcast
             for (int t = 0; t < cnt; ++t) {
                 const float4 pn = stage[wslot][buf][(t + 1) & 63];  // the next partner lands behind this one's math
-                pair_evals<IPT, 0, false>(xi, yi, zi, mi, axi, ayi, azi, pj.x, pj.y, pj.z, pj.w, dummy_x, dummy_y,
-                                          dummy_z, eps2v);
+                if (PK)
+                    pair_evals_pk<IPT / 2, 0, false>(xi2, yi2, zi2, mi2, axi2, ayi2, azi2, pj.x, pj.y, pj.z, pj.w, dummy2,
+                                                     dummy2, dummy2, eps2v);
+                else
+                    pair_evals<IPT, 0, false>(xi, yi, zi, mi, axi, ayi, azi, pj.x, pj.y, pj.z, pj.w, dummy_x, dummy_y,
+                                              dummy_z, eps2v);
                 pj = pn;
             }
             buf ^= 1;
@@ -279,6 +278,7 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_os(const float4* __restrict__ p
         }
         seg_first += ns;
     }
+    if (PK) { unpack_pairs<IPT>(axi2, axi); unpack_pairs<IPT>(ayi2, ayi); unpack_pairs<IPT>(azi2, azi); }
     float4* __restrict__ out = planes + size_t(part) * plane_stride;
 #pragma unroll
     for (int q = 0; q < IPT; ++q) out[size_t(a * IPT + q) * 64 + lane] = make_float4(axi[q], ayi[q], azi[q], 0.f);
@@ -471,8 +471,12 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
 void launch_bf_os(hipStream_t s, const Shard& sh, int A, int K, float4* planes, size_t plane_stride, float g_soft2) {
     if (A <= 0 || K <= 0) return;
     const int wpb = 12;
-    hipLaunchKernelGGL((k_bf_os<8, 12>), dim3((A * K + wpb - 1) / wpb), dim3(wpb * 64), 0, s, sh.pos_all, sh.seg_count,
-                       sh.n_seg, sh.seg_cap, sh.my_seg, A, K, planes, plane_stride, g_soft2);
+    if (nbody_sym_packed)
+        hipLaunchKernelGGL((k_bf_os<8, 12, true>), dim3((A * K + wpb - 1) / wpb), dim3(wpb * 64), 0, s, sh.pos_all,
+                           sh.seg_count, sh.n_seg, sh.seg_cap, sh.my_seg, A, K, planes, plane_stride, g_soft2);
+    else
+        hipLaunchKernelGGL((k_bf_os<8, 12, false>), dim3((A * K + wpb - 1) / wpb), dim3(wpb * 64), 0, s, sh.pos_all,
+                           sh.seg_count, sh.n_seg, sh.seg_cap, sh.my_seg, A, K, planes, plane_stride, g_soft2);
 }
 
 // the fixed-order sum of the planes into acc (the own/opposite-set pairs ride on the rotation
