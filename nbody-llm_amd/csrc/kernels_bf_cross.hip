@@ -99,20 +99,27 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_cross(const float4* __restrict_
             case 1: __builtin_amdgcn_s_setprio(1); break;
             default: __builtin_amdgcn_s_setprio(0); break;
         }
-        float x1 = rotl(xj, src_lane), y1 = rotl(yj, src_lane), z1 = rotl(zj, src_lane), m1 = rotl(mj, src_lane);
-#pragma unroll 2
-        for (int st = 0; st < 64; ++st) {
-            const float x2 = rotl(xj, src_lane2), y2 = rotl(yj, src_lane2), z2 = rotl(zj, src_lane2), m2 = rotl(mj, src_lane2);
-            if (PK) {
+        if (PK) {  // one step ahead, two steps per iteration: the two register sets swap roles (see k_bf_sym)
+            for (int st = 0; st < 64; st += 2) {
+                const float x1 = rotl(xj, src_lane), y1 = rotl(yj, src_lane), z1 = rotl(zj, src_lane), m1 = rotl(mj, src_lane);
                 pair_evals_pk<IPT / 2, 0, true>(xi2, yi2, zi2, mi2, axi2, ayi2, azi2, xj, yj, zj, mj, axj2, ayj2, azj2, eps2v);
                 axj2.x = rotl(axj2.x, src_lane); ayj2.x = rotl(ayj2.x, src_lane); azj2.x = rotl(azj2.x, src_lane);
                 axj2.y = rotl(axj2.y, src_lane); ayj2.y = rotl(ayj2.y, src_lane); azj2.y = rotl(azj2.y, src_lane);
-            } else {
+                xj = rotl(x1, src_lane); yj = rotl(y1, src_lane); zj = rotl(z1, src_lane); mj = rotl(m1, src_lane);
+                pair_evals_pk<IPT / 2, 0, true>(xi2, yi2, zi2, mi2, axi2, ayi2, azi2, x1, y1, z1, m1, axj2, ayj2, azj2, eps2v);
+                axj2.x = rotl(axj2.x, src_lane); ayj2.x = rotl(ayj2.x, src_lane); azj2.x = rotl(azj2.x, src_lane);
+                axj2.y = rotl(axj2.y, src_lane); ayj2.y = rotl(ayj2.y, src_lane); azj2.y = rotl(azj2.y, src_lane);
+            }
+        } else {
+            float x1 = rotl(xj, src_lane), y1 = rotl(yj, src_lane), z1 = rotl(zj, src_lane), m1 = rotl(mj, src_lane);
+#pragma unroll 2
+            for (int st = 0; st < 64; ++st) {
+                const float x2 = rotl(xj, src_lane2), y2 = rotl(yj, src_lane2), z2 = rotl(zj, src_lane2), m2 = rotl(mj, src_lane2);
                 pair_evals<IPT, 0, true>(xi, yi, zi, mi, axi, ayi, azi, xj, yj, zj, mj, axj, ayj, azj, eps2v);
                 axj = rotl(axj, src_lane); ayj = rotl(ayj, src_lane); azj = rotl(azj, src_lane);
+                xj = x1; yj = y1; zj = z1; mj = m1;
+                x1 = x2; y1 = y2; z1 = z2; m1 = m2;
             }
-            xj = x1; yj = y1; zj = z1; mj = m1;
-            x1 = x2; y1 = y2; z1 = z2; m1 = m2;
         }
         if (PK) { axj = axj2.x + axj2.y; ayj = ayj2.x + ayj2.y; azj = azj2.x + azj2.y; }
         xplanes[(size_t(pi) * A + a) * plane_stride + size_t(c) * 64 + lane] = make_float4(axj, ayj, azj, 0.f);

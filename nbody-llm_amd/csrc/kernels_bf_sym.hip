@@ -127,23 +127,32 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
             case 1: __builtin_amdgcn_s_setprio(1); break;
             default: __builtin_amdgcn_s_setprio(0); break;
         }
-        // positions are rotated two steps ahead (they do not change while the chunk travels), so the
-        // crossbar latency never sits between a rotate and its first use
-        float x1 = rotl(xj, src_lane), y1 = rotl(yj, src_lane), z1 = rotl(zj, src_lane), m1 = rotl(mj, src_lane);
-#pragma unroll 2
-        for (int s = 0; s < 64; ++s) {
-            const float x2 = rotl(xj, src_lane2), y2 = rotl(yj, src_lane2), z2 = rotl(zj, src_lane2), m2 = rotl(mj, src_lane2);
-            if (PK) {
+        if (PK) {
+            // the next step's positions are requested at the start of this one (they arrive long before
+            // its end); two steps per iteration so that the two register sets swap roles without moves
+            for (int s = 0; s < 64; s += 2) {
+                const float x1 = rotl(xj, src_lane), y1 = rotl(yj, src_lane), z1 = rotl(zj, src_lane), m1 = rotl(mj, src_lane);
                 pair_evals_pk<IPT / 2, DBG>(xi2, yi2, zi2, mi2, axi2, ayi2, azi2, xj, yj, zj, mj, axj2, ayj2, azj2, eps2v);
+                // the accumulators follow their body; they are next needed at the END of the next step
                 axj2.x = rotl(axj2.x, src_lane); ayj2.x = rotl(ayj2.x, src_lane); azj2.x = rotl(azj2.x, src_lane);
                 axj2.y = rotl(axj2.y, src_lane); ayj2.y = rotl(ayj2.y, src_lane); azj2.y = rotl(azj2.y, src_lane);
-            } else {
-                pair_evals<IPT, DBG>(xi, yi, zi, mi, axi, ayi, azi, xj, yj, zj, mj, axj, ayj, azj, eps2v);
-                // the accumulators follow their body; they are next needed at the END of the next step
-                axj = rotl(axj, src_lane); ayj = rotl(ayj, src_lane); azj = rotl(azj, src_lane);
+                xj = rotl(x1, src_lane); yj = rotl(y1, src_lane); zj = rotl(z1, src_lane); mj = rotl(m1, src_lane);
+                pair_evals_pk<IPT / 2, DBG>(xi2, yi2, zi2, mi2, axi2, ayi2, azi2, x1, y1, z1, m1, axj2, ayj2, azj2, eps2v);
+                axj2.x = rotl(axj2.x, src_lane); ayj2.x = rotl(ayj2.x, src_lane); azj2.x = rotl(azj2.x, src_lane);
+                axj2.y = rotl(axj2.y, src_lane); ayj2.y = rotl(ayj2.y, src_lane); azj2.y = rotl(azj2.y, src_lane);
             }
-            xj = x1; yj = y1; zj = z1; mj = m1;
-            x1 = x2; y1 = y2; z1 = z2; m1 = m2;
+        } else {
+            // positions are rotated two steps ahead (they do not change while the chunk travels), so the
+            // crossbar latency never sits between a rotate and its first use
+            float x1 = rotl(xj, src_lane), y1 = rotl(yj, src_lane), z1 = rotl(zj, src_lane), m1 = rotl(mj, src_lane);
+#pragma unroll 2
+            for (int s = 0; s < 64; ++s) {
+                const float x2 = rotl(xj, src_lane2), y2 = rotl(yj, src_lane2), z2 = rotl(zj, src_lane2), m2 = rotl(mj, src_lane2);
+                pair_evals<IPT, DBG>(xi, yi, zi, mi, axi, ayi, azi, xj, yj, zj, mj, axj, ayj, azj, eps2v);
+                axj = rotl(axj, src_lane); ayj = rotl(ayj, src_lane); azj = rotl(azj, src_lane);
+                xj = x1; yj = y1; zj = z1; mj = m1;
+                x1 = x2; y1 = y2; z1 = z2; m1 = m2;
+            }
         }
         if (PK) { axj = axj2.x + axj2.y; ayj = ayj2.x + ayj2.y; azj = azj2.x + azj2.y; }
         const int d = k / IPT + 1;  // set distance 1..sym_sets
