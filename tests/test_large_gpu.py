@@ -55,3 +55,37 @@ def test_barnes_hut_one_million_bodies_counts_and_accelerations(gpu, orc):
         s = sim.stats()
     assert (s.interactions, s.node_visits) == (acc_n, vis_n)
     assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+
+
+def test_barnes_hut_four_million_bodies_host_and_device_tree(gpu, orc):
+    """configs[4]'s 4 194 304 bodies, theta = 0.5, on one GPU.  Host build + strict walk: accepted and
+    visited node counts equal the threaded oracle's exactly, accelerations to rounding.  Device build
+    (kernels_tree.hip): same cells, centres of mass from f64 prefix sums instead of the reference's
+    sequential f32 folds, so a few opening tests sit on the other side of their threshold -- counts
+    within 1e-3; a flipped test moves one body's acceleration by that node's
+    multipole error (or, for a leaf, by its whole contribution: the reference drops leaves that fail
+    the test), so accelerations are compared as a distribution: 99.9 % of the bodies within 1e-5 of
+    the host-tree walk, none beyond 1e-2."""
+    nb = gpu
+    n = 1 << 22
+    sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(n, seed=11)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=16)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        host = sim.get_points()["acceleration"]
+        s = sim.stats()
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    assert rel_err(host, ref["acceleration"]) < 1e-5
+    del ref
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        dev = sim.get_points()["acceleration"]
+        sdev = sim.stats()
+    assert abs(sdev.interactions - acc_n) < 1e-3 * acc_n and abs(sdev.node_visits - vis_n) < 1e-3 * vis_n
+    assert sdev.tree_nodes == s.tree_nodes
+    dev_err = np.abs(dev.astype(np.float64) - host).max(axis=1) / np.abs(host).max()
+    assert np.quantile(dev_err, 0.999) < 1e-5 and dev_err.max() < 1e-2, (np.quantile(dev_err, 0.999), dev_err.max())
