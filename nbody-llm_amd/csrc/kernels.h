@@ -109,7 +109,19 @@ struct TreeDevWork {  // arrays of the last build the split-point kernel needs
     const signed char* delta = nullptr;
     const int* base = nullptr;
 };
+struct TreeCat {  // sharded runs: side buffer of the device build
+    float4* pos = nullptr;     // live bodies of all segments, concatenated in segment order
+    int* flags = nullptr;
+    int* base = nullptr;
+    int* own_order = nullptr;  // own bodies in tree order, indices into the own segment
+    int* info = nullptr;       // [0] total bodies, [1] first own body in the concatenation, [2] own count
+};
 size_t tree_build_workspace_bytes(size_t n_cap);
+size_t tree_build_tmp_bytes(size_t n_cap);
+size_t tree_cat_bytes(size_t n_cap);
+TreeCat tree_cat_layout(void* buf, size_t n_cap);
+void launch_tree_cat(hipStream_t s, const Shard& sh, const TreeCat& c);
+int launch_tree_own_order(hipStream_t s, const int* order, const TreeCat& c, int n_total_upper, void* tmp, size_t tmp_bytes);
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
                         int* out_info, TreeDevWork* work);

@@ -187,17 +187,150 @@ __global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, co
     anc[s * max_anc + a] = base[kf] + (a - (dp + 1));
 }
 
+// ---- inclusive scan of Sum4 with a FIXED association order.  rocPRIM's decoupled look-back scan
+// combines the partial sums of earlier blocks in whatever grouping their completion order allows;
+// f64 addition is not associative, so a centre of mass would now and then differ in its last f32 bit
+// from one run to the next (seen: 1 node in 30 000, every few builds).  Three passes instead: block
+// totals (1024 items per block), a one-block scan of the totals, block-local scans with carry-in.
+constexpr int kScanThreads = 256, kScanItems = 4, kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ Sum4 sum4_add(const Sum4& a, const Sum4& b) { return Sum4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
+
+// inclusive scan of one value per thread over the block (Hillis-Steele in LDS: a fixed pattern)
+template <int THREADS>
+__device__ __forceinline__ Sum4 block_inclusive_scan(Sum4 v, Sum4* lds) {
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < THREADS; off <<= 1) {
+        Sum4 add = Sum4{0.0, 0.0, 0.0, 0.0};
+        const bool has = t >= off;
+        if (has) add = lds[t - off];
+        __syncthreads();
+        if (has) { v = sum4_add(add, v); lds[t] = v; }
+        __syncthreads();
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_sum4_block_totals(const Sum4* __restrict__ in, const int* __restrict__ count,
+                                                                     Sum4* __restrict__ totals) {
+    __shared__ Sum4 lds[kScanThreads];
+    const int n = *count;
+    const int i0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    Sum4 v = Sum4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) if (i0 + q < n) v = sum4_add(v, in[i0 + q]);
+    v = block_inclusive_scan<kScanThreads>(v, lds);
+    if (threadIdx.x == kScanThreads - 1) totals[blockIdx.x] = v;
+}
+
+// exclusive scan of the block totals, one workgroup; prefix[b] = sum of totals[0..b-1]
+__global__ __launch_bounds__(1024) void k_sum4_scan_totals(const Sum4* __restrict__ totals, int n_blocks,
+                                                            Sum4* __restrict__ prefix) {
+    __shared__ Sum4 lds[1024];
+    const int per = (n_blocks + 1023) / 1024;
+    const int b0 = threadIdx.x * per;
+    Sum4 v = Sum4{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < per; ++q) if (b0 + q < n_blocks) v = sum4_add(v, totals[b0 + q]);
+    const Sum4 incl = block_inclusive_scan<1024>(v, lds);
+    // exclusive prefix of this thread's first block = inclusive of the previous thread
+    __syncthreads();
+    lds[threadIdx.x] = incl;
+    __syncthreads();
+    Sum4 run = threadIdx.x > 0 ? lds[threadIdx.x - 1] : Sum4{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < per; ++q)
+        if (b0 + q < n_blocks) { prefix[b0 + q] = run; run = sum4_add(run, totals[b0 + q]); }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_sum4_block_scan(const Sum4* __restrict__ in, const int* __restrict__ count,
+                                                                   const Sum4* __restrict__ prefix, Sum4* __restrict__ out) {
+    __shared__ Sum4 lds[kScanThreads];
+    const int n = *count;
+    const int i0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    Sum4 item[kScanItems];
+    Sum4 v = Sum4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) {
+        item[q] = (i0 + q < n) ? in[i0 + q] : Sum4{0.0, 0.0, 0.0, 0.0};
+        v = sum4_add(v, item[q]);
+    }
+    const Sum4 incl = block_inclusive_scan<kScanThreads>(v, lds);
+    __syncthreads();
+    lds[threadIdx.x] = incl;
+    __syncthreads();
+    Sum4 run = sum4_add(prefix[blockIdx.x], threadIdx.x > 0 ? lds[threadIdx.x - 1] : Sum4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) {
+        run = sum4_add(run, item[q]);
+        if (i0 + q < n) out[i0 + q] = run;
+    }
+}
+
+// bytes of scratch the three passes need for n_cap items
+size_t sum4_scan_tmp_bytes(size_t n_cap) { return 2 * ((n_cap + kScanTile - 1) / kScanTile + 1) * sizeof(Sum4); }
+
+void sum4_inclusive_scan(hipStream_t s, void* tmp, const Sum4* in, Sum4* out, const int* d_count, int n_upper) {
+    const int n_blocks = (n_upper + kScanTile - 1) / kScanTile;
+    Sum4* totals = static_cast<Sum4*>(tmp);
+    Sum4* prefix = totals + n_blocks + 1;
+    hipLaunchKernelGGL(k_sum4_block_totals, dim3(n_blocks), dim3(kScanThreads), 0, s, in, d_count, totals);
+    hipLaunchKernelGGL(k_sum4_scan_totals, dim3(1), dim3(1024), 0, s, totals, n_blocks, prefix);
+    hipLaunchKernelGGL(k_sum4_block_scan, dim3(n_blocks), dim3(kScanThreads), 0, s, in, d_count, prefix, out);
+}
+
+// scratch at the start of the build workspace: whatever the rocPRIM sort / integer scan or the Sum4
+// scan asks for, whichever is largest
+size_t scratch_bytes(size_t n_cap) {
+    size_t sort_bytes = 0, scan_i = 0;
+    unsigned long long* k = nullptr; int* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 63, 0);
+    (void)rocprim::exclusive_scan(nullptr, scan_i, v, v, 0, n_cap, rocprim::plus<int>(), 0);
+    return (std::max(sort_bytes, std::max(scan_i, sum4_scan_tmp_bytes(n_cap))) + 255) / 256 * 256;
+}
+
+// ---- sharded runs: the tree is built over the live bodies of ALL segments (every GPU builds the
+// same tree from the gathered positions and walks it for its own bodies)
+// live bodies of the segments, concatenated in segment order; info[0] = total, info[1] = index of the
+// own segment's first body in the concatenation, info[2] = own count
+__global__ __launch_bounds__(256) void k_tree_cat(const float4* __restrict__ pos_all, const int* __restrict__ seg_count,
+                                                  int n_seg, int seg_cap, int my_seg, float4* __restrict__ pos_cat,
+                                                  int* __restrict__ info) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int sgm = idx / seg_cap, j = idx - sgm * seg_cap;
+    if (sgm >= n_seg) return;
+    int first = 0, own_first = 0, total = 0;
+    for (int t = 0; t < n_seg; ++t) {
+        if (t == sgm) first = total;
+        if (t == my_seg) own_first = total;
+        total += seg_count[t];
+    }
+    if (idx == 0) { info[0] = total; info[1] = own_first; info[2] = seg_count[my_seg]; }
+    if (j < seg_count[sgm]) pos_cat[first + j] = pos_all[size_t(sgm) * seg_cap + j];
+}
+
+// tree-order list of all bodies -> flags of the own ones
+__global__ __launch_bounds__(256) void k_tree_own_flags(const int* __restrict__ order, const int* __restrict__ info,
+                                                        int* __restrict__ flags) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= info[0]) return;
+    const int rel = order[k] - info[1];
+    flags[k] = (rel >= 0 && rel < info[2]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_tree_own_scatter(const int* __restrict__ order, const int* __restrict__ info,
+                                                          const int* __restrict__ flags, const int* __restrict__ base,
+                                                          int* __restrict__ own_order) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= info[0]) return;
+    if (flags[k]) own_order[base[k]] = order[k] - info[1];  // index inside the own segment
+}
+
 }  // namespace
 
 size_t tree_build_workspace_bytes(size_t n_cap) {
-    size_t sort_bytes = 0, scan_i = 0, scan_s = 0;
-    unsigned long long* k = nullptr; int* v = nullptr; Sum4* s = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 63, 0);
-    (void)rocprim::exclusive_scan(nullptr, scan_i, v, v, 0, n_cap, rocprim::plus<int>(), 0);
-    (void)rocprim::inclusive_scan(nullptr, scan_s, s, s, n_cap, Sum4Plus(), 0);
-    const size_t tmp = std::max(sort_bytes, std::max(scan_i, scan_s));
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    return al(tmp) + 2 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
+    return scratch_bytes(n_cap) + 2 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
 }
 
 // Enqueues the whole build on `s`.  out_info (device, 2 ints): [0] = node count, [1] = flags
@@ -207,14 +340,7 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
                         int* out_info, TreeDevWork* work) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     char* p = static_cast<char*>(workspace);
-    size_t sort_bytes = 0, scan_i = 0, scan_s = 0;
-    {
-        unsigned long long* k = nullptr; int* v = nullptr; Sum4* q = nullptr;
-        (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 63, 0);
-        (void)rocprim::exclusive_scan(nullptr, scan_i, v, v, 0, n_cap, rocprim::plus<int>(), 0);
-        (void)rocprim::inclusive_scan(nullptr, scan_s, q, q, n_cap, Sum4Plus(), 0);
-    }
-    size_t tmp_bytes = al(std::max(sort_bytes, std::max(scan_i, scan_s)));
+    const size_t tmp_bytes = scratch_bytes(n_cap);
     void* tmp = p; p += tmp_bytes;
     auto* keys_in = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
     auto* keys = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
@@ -237,8 +363,7 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
         hipLaunchKernelGGL(k_tree_delta, grid, block, 0, s, keys, ids, pos, d_count, delta, emit_count, sums, out_info + 1);
         tb = tmp_bytes;
         if (rocprim::exclusive_scan(tmp, tb, emit_count, base, 0, size_t(n), rocprim::plus<int>(), s) != hipSuccess) return -1;
-        tb = tmp_bytes;
-        if (rocprim::inclusive_scan(tmp, tb, sums, incl, size_t(n), Sum4Plus(), s) != hipSuccess) return -1;
+        sum4_inclusive_scan(s, tmp, sums, incl, d_count, n);
     }
     hipLaunchKernelGGL(k_tree_emit, grid, block, 0, s, keys, ids, pos, d_count, delta, base, incl, width, nodes, node_cap,
                        order, out_info);
@@ -249,6 +374,45 @@ void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_
                            int* n_anc, int* anc, int max_anc) {
     hipLaunchKernelGGL(k_tree_split_anc, dim3(n_split), dim3(32), 0, s, work.keys, work.delta, work.base, n, n_nodes,
                        n_split, first, n_anc, anc, max_anc);
+}
+
+// bytes at the start of the build workspace that rocPRIM uses as scratch (free between builds)
+size_t tree_build_tmp_bytes(size_t n_cap) { return scratch_bytes(n_cap); }
+
+// sharded runs: bytes of the side buffer (concatenated positions, own-order flags/offsets/list, info)
+size_t tree_cat_bytes(size_t n_cap) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    return al(n_cap * sizeof(float4)) + 3 * al(n_cap * 4) + 256;
+}
+
+TreeCat tree_cat_layout(void* buf, size_t n_cap) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    char* p = static_cast<char*>(buf);
+    TreeCat c;
+    c.pos = reinterpret_cast<float4*>(p); p += al(n_cap * sizeof(float4));
+    c.flags = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    c.base = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    c.own_order = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    c.info = reinterpret_cast<int*>(p);
+    return c;
+}
+
+void launch_tree_cat(hipStream_t s, const Shard& sh, const TreeCat& c) {
+    const int slots = sh.n_seg * sh.seg_cap;
+    hipLaunchKernelGGL(k_tree_cat, dim3((slots + 255) / 256), dim3(256), 0, s, sh.pos_all, sh.seg_count, sh.n_seg, sh.seg_cap,
+                       sh.my_seg, c.pos, c.info);
+}
+
+// own bodies in tree order, as indices into the own segment (tmp: the build's workspace, free again)
+int launch_tree_own_order(hipStream_t s, const int* order, const TreeCat& c, int n_total_upper, void* tmp, size_t tmp_bytes) {
+    if (n_total_upper <= 0) return 0;
+    const dim3 grid((n_total_upper + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_tree_own_flags, grid, block, 0, s, order, c.info, c.flags);
+    size_t tb = tmp_bytes;
+    // (entries beyond the live total are never read back: flags there may be stale, their offsets unused)
+    if (rocprim::exclusive_scan(tmp, tb, c.flags, c.base, 0, size_t(n_total_upper), rocprim::plus<int>(), s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_tree_own_scatter, grid, block, 0, s, order, c.info, c.flags, c.base, c.own_order);
+    return 0;
 }
 
 }  // namespace nbody

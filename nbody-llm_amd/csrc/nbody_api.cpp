@@ -64,6 +64,7 @@ struct NbodyHandle {
     int* h_counts = nullptr;   // pinned: all segments' counts
     std::vector<int32_t> own_order;
     void* d_tree_ws = nullptr;   // device-build workspace (keys, sort buffers, scans)
+    void* d_tree_cat = nullptr;  // sharded device build: concatenated positions, own-order list
     size_t tree_ws_cap = 0;      // bodies it is sized for
     int* d_tree_info = nullptr;  // [2] node count, flags
     int* h_tree_info = nullptr;  // pinned
@@ -420,7 +421,7 @@ int bh_forces(NbodyHandle* h) {
         int rc = exchange_wait(h);
         if (rc) return rc;
     }
-    if (h->cfg.tree_build == NBODY_TREE_DEVICE && sh.n_seg == 1) {
+    if (h->cfg.tree_build == NBODY_TREE_DEVICE) {
         bool fell_back = false;
         int rc = bh_walk_device_tree(h, &fell_back);
         if (rc || !fell_back) return rc;
@@ -543,40 +544,60 @@ int bh_forces(NbodyHandle* h) {
 int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     Shard& sh = h->sh;
     auto t1 = clk::now();
-    const size_t n_cap = size_t(sh.seg_cap);
+    const bool sharded = sh.n_seg > 1;
+    const size_t n_cap = size_t(sh.seg_cap) * sh.n_seg;  // the tree holds the bodies of every segment
     if (h->tree_ws_cap < n_cap) {
         if (h->d_tree_ws) (void)hipFree(h->d_tree_ws);
-        h->d_tree_ws = nullptr; h->tree_ws_cap = 0;
+        if (h->d_tree_cat) (void)hipFree(h->d_tree_cat);
+        h->d_tree_ws = nullptr; h->d_tree_cat = nullptr; h->tree_ws_cap = 0;
         HIP_TRY(h, hipMalloc(&h->d_tree_ws, nbody::tree_build_workspace_bytes(n_cap)));
+        if (sharded) HIP_TRY(h, hipMalloc(&h->d_tree_cat, nbody::tree_cat_bytes(n_cap)));
         h->tree_ws_cap = n_cap;
     }
     if (!h->d_tree_info) {
         HIP_TRY(h, hipMalloc(&h->d_tree_info, 2 * sizeof(int)));
         HIP_TRY(h, hipHostMalloc(&h->h_tree_info, 2 * sizeof(int), hipHostMallocDefault));
     }
+    const size_t tot_upper = total_upper(h);
     // a Plummer sphere gives ~1.5 nodes per body; 4 per body + the count read-back below catch the rest
-    int rc = ensure_tree_dev(h, std::max<size_t>(h->d_node_cap, 4 * h->n_local + 64), h->n_local);
+    int rc = ensure_tree_dev(h, std::max<size_t>(h->d_node_cap, 4 * tot_upper + 64), tot_upper);
     if (rc) return rc;
+    nbody::TreeCat cat;
+    const float4* tree_pos = sh.own_pos();
+    const int* tree_count = sh.own_count();
+    if (sharded) {  // every GPU builds the same tree over the gathered bodies of all segments
+        cat = nbody::tree_cat_layout(h->d_tree_cat, n_cap);
+        nbody::launch_tree_cat(h->stream, sh, cat);
+        tree_pos = cat.pos;
+        tree_count = cat.info;
+    }
     nbody::TreeDevWork work;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (nbody::build_octree_device(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->center, h->width,
+        if (nbody::build_octree_device(h->stream, tree_pos, tree_count, int(tot_upper), h->center, h->width,
                                        h->d_tree_ws, n_cap, h->d_nodes, int(h->d_node_cap), h->d_order, h->d_tree_info,
                                        &work) != 0)
             return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(h->h_tree_info, h->d_tree_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int) * sh.n_seg, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (!(h->h_tree_info[1] & 2)) break;
-        rc = ensure_tree_dev(h, size_t(h->h_tree_info[0]) + 64, h->n_local);  // more nodes than allowed for: grow, rebuild
+        rc = ensure_tree_dev(h, size_t(h->h_tree_info[0]) + 64, tot_upper);  // more nodes than allowed for: grow, rebuild
         if (rc) return rc;
     }
-    h->seg_count_host[0] = h->h_counts[0];
-    h->n_local = size_t(h->h_counts[0]);
+    for (int s = 0; s < sh.n_seg; ++s) h->seg_count_host[s] = h->h_counts[s];
+    h->n_local = size_t(h->h_counts[sh.my_seg]);
     h->count_dirty = false;
     if (h->h_tree_info[1] & 1) { *fell_back = true; return NBODY_OK; }
     const int n_nodes = h->h_tree_info[0];
-    const size_t n_order = h->n_local;
+    const size_t n_order = h->n_local;             // bodies this GPU walks
+    const size_t n_tree = total_upper(h);          // bodies in the tree (now exact)
+    const int* d_walk_order = h->d_order;
+    if (sharded) {
+        if (nbody::launch_tree_own_order(h->stream, h->d_order, cat, int(n_tree), h->d_tree_ws, nbody::tree_build_tmp_bytes(n_cap)) != 0)
+            return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
+        d_walk_order = cat.own_order;
+    }
     h->stats.tree_build_ms += ms_since(t1);
     h->stats.tree_nodes = uint64_t(n_nodes);
     h->tree_on_device = true;
@@ -593,13 +614,13 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     if (n_order == 0) K = 1;
     nbody::TreeDev td;
     td.nodes = h->d_nodes; td.n_nodes = n_nodes;
-    td.order = h->d_order; td.n_order = int(n_order);
+    td.order = d_walk_order; td.n_order = int(n_order);
     td.n_split = K;
     td.split_first = h->d_split;
     td.split_n_anc = h->d_split + kMaxSplit + 1;
     td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
-    if (n_order > 0)
-        nbody::launch_tree_split_anc(h->stream, work, int(n_order), n_nodes, K, h->d_split, h->d_split + kMaxSplit + 1,
+    if (n_tree > 0)
+        nbody::launch_tree_split_anc(h->stream, work, int(n_tree), n_nodes, K, h->d_split, h->d_split + kMaxSplit + 1,
                                      h->d_split + kMaxSplit + 1 + kMaxSplit, kMaxAnc);
     if (K > 1) {
         const size_t need = size_t(K) * sh.seg_cap;
@@ -737,7 +758,7 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_tree_ws, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
+                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_tree_ws, h->d_tree_cat, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info};
     for (void* p : host) if (p) (void)hipHostFree(p);

@@ -13,8 +13,8 @@ BOX = ((0.0, 0.0, 0.0), 64.0)
 FIELDS = ("position", "velocity", "acceleration", "mass")
 
 
-def make_world(nb, ics, G, box, st, method, math_mode):
-    sims = [nb.Simulation(ics, *box, method=method, math_mode=math_mode, rank=r, world_size=G, capacity=len(ics))
+def make_world(nb, ics, G, box, st, method, math_mode, **kw):
+    sims = [nb.Simulation(ics, *box, method=method, math_mode=math_mode, rank=r, world_size=G, capacity=len(ics), **kw)
             for r in range(G)]
     for s in sims:
         s.settings = st
@@ -160,6 +160,44 @@ def test_barnes_hut_shards_match_single(gpu, orc, G):
     assert sum(s.interactions for s in stats) == tot_a and sum(s.node_visits for s in stats) == tot_v
     assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
     assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    for s in sims:
+        s.close()
+
+
+@pytest.mark.parametrize("G,n,box_w", [(2, 3000, 64.0), (4, 20000, 64.0), (3, 9000, 2.5)])
+def test_barnes_hut_shards_with_device_tree_equal_single_shard(gpu, G, n, box_w):
+    """Device-side build in a sharded world: every GPU concatenates the gathered segments, builds the
+    same tree and walks it for its own bodies.  Same tree + same per-body walk => the state equals the
+    1-shard device-tree run bit for bit and the node counts add up exactly (bodies leave the 2.5-wide
+    box on the way: per-segment counts, concatenation offsets and own-order lists all move).  The walk's
+    node-range split is pinned to 8 segments: its default follows the number of own bodies, and the
+    order in which the segments' partial sums are added would differ between the two runs."""
+    import ctypes
+    nb = gpu
+    split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    split.value = 8
+    box = ((0.0, 0.0, 0.0), box_w)
+    st = nb.Settings(1.0, 0.01, 5e-3, 0.25)
+    ics = nb.plummer(n, seed=31)
+    sims = make_world(nb, ics, G, box, st, nb.BARNES_HUT, nb.FAST, tree_build=nb.TREE_DEVICE)
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as one:
+        one.settings = st
+        one.init()
+        for _ in range(5):
+            nb.sharded_step(sims)
+            one.step()
+        ref = one.get_points()
+        s1 = one.stats()
+    split.value = 0
+    got = gather(sims)
+    stats = [s.stats() for s in sims]
+    if box_w < 10:
+        assert len(ref) < n
+    assert len(got) == len(ref)
+    for f in FIELDS:
+        assert np.array_equal(got[f], ref[f]), f
+    assert sum(s.interactions for s in stats) == s1.interactions and sum(s.node_visits for s in stats) == s1.node_visits
+    assert all(s.tree_nodes == s1.tree_nodes for s in stats)
     for s in sims:
         s.close()
 
