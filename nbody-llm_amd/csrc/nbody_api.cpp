@@ -27,6 +27,7 @@ extern "C" int nbody_sym_wpb;
 extern "C" int nbody_sym_rounds;
 extern "C" int nbody_sym_packed;
 extern "C" int nbody_bh_walk_split;
+extern "C" int nbody_bh_walk_variant;
 extern "C" int nbody_cross_sym = 1;  // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided
 
 using nbody::BoundsF;
@@ -835,6 +836,8 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
     if (const char* v = std::getenv("NBODY_CROSS_SYM")) nbody_cross_sym = std::atoi(v);
     if (const char* v = std::getenv("NBODY_SYM_PACKED")) nbody_sym_packed = std::atoi(v);
+    if (const char* v = std::getenv("NBODY_BH_VARIANT")) nbody_bh_walk_variant = std::atoi(v);
+    if (const char* v = std::getenv("NBODY_BH_SPLIT")) nbody_bh_walk_split = std::atoi(v);
     if (const char* v = std::getenv("NBODY_SYM_WPB")) nbody_sym_wpb = std::atoi(v);
     *out = h;
     return NBODY_OK;

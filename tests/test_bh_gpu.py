@@ -104,6 +104,35 @@ def test_fast_math_walk_same_nodes(gpu, orc):
     assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("math", ["strict", "fast"])
+@pytest.mark.parametrize("n,split", [(3001, 0), (777, 1), (20000, 4)])
+def test_alternative_walk_kernels_same_nodes(gpu, orc, variant, math, n, split):
+    """The selectable walk kernels -- 1: wave-cooperative (one scalar node load per wave), 2: two lanes
+    per body (one contiguous 32-byte request per visit) -- evaluate exactly the opening tests of the
+    default one: node counts equal the oracle's, accelerations to rounding.  Odd body counts leave a
+    half-filled last lane pair."""
+    import ctypes
+    nb = gpu
+    sd, st = sd_st(nb, theta2=0.25, g_soft=0.01)
+    ics = nb.plummer(n, seed=33)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4)
+    var = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_variant")
+    spl = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    var.value, spl.value = variant, split
+    try:
+        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT if math == "strict" else nb.FAST) as sim:
+            sim.settings = st
+            sim.update_forces()
+            got = sim.get_points()
+            s = sim.stats()
+    finally:
+        var.value, spl.value = 0, 0
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+
+
 def test_retain_in_a_tight_box(gpu, orc):
     nb = gpu
     box = ((0.0, 0.0, 0.0), 2.0)
