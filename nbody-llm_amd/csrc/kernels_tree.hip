@@ -39,8 +39,10 @@ struct Sum4Plus {
 
 __global__ __launch_bounds__(256) void k_tree_keys(const float4* __restrict__ pos, const int* __restrict__ count,
                                                    int n_upper, float cx0, float cy0, float cz0, float width,
-                                                   unsigned long long* __restrict__ keys, int* __restrict__ ids) {
+                                                   unsigned long long* __restrict__ keys, int* __restrict__ ids,
+                                                   int* __restrict__ out_info) {
     const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) { out_info[0] = 0; out_info[1] = 0; }  // node count and flags of this build (first kernel of the build)
     if (k >= n_upper) return;
     if (k >= *count) {  // n_upper only bounds the live count: the unused tail sorts to the end (bit 63 set),
         keys[k] = ~0ull;  // where every later kernel ignores it (they all read *count)
@@ -105,10 +107,12 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
                 nodes[1] = make_float4(width * width, __int_as_float(1), width, __int_as_float(-1));
             }
             out_info[0] = 1;
+            out_info[2] = 0;
         }
         return;
     }
     if (k >= n) return;
+    if (k == 0) out_info[2] = n;  // the live body count rides along with the node count (one read-back)
     const int d_next = delta[k];
     const int d_prev = (k > 0) ? delta[k - 1] : -1;
     const int opened = max(0, d_next - d_prev);
@@ -333,7 +337,7 @@ size_t tree_build_workspace_bytes(size_t n_cap) {
     return scratch_bytes(n_cap) + 2 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
 }
 
-// Enqueues the whole build on `s`.  out_info (device, 2 ints): [0] = node count, [1] = flags
+// Enqueues the whole build on `s`.  out_info (device, 3 ints): [0] = node count, [1] = flags, [2] = bodies in the tree
 // (1: deeper than 21 levels, 2: node_cap too small).  The caller reads it back before the walk.
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
@@ -353,11 +357,11 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
     auto* incl = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
     work->keys = keys; work->delta = delta; work->base = base;
 
-    (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s);
     const int n = n_upper;
+    if (n <= 0) (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s);  // (k_tree_keys clears it otherwise)
     const dim3 grid(std::max(1, (n + 255) / 256)), block(256);
     if (n > 0) {
-        hipLaunchKernelGGL(k_tree_keys, grid, block, 0, s, pos, d_count, n, center[0], center[1], center[2], width, keys_in, ids_in);
+        hipLaunchKernelGGL(k_tree_keys, grid, block, 0, s, pos, d_count, n, center[0], center[1], center[2], width, keys_in, ids_in, out_info);
         size_t tb = tmp_bytes;
         if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys, ids_in, ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_tree_delta, grid, block, 0, s, keys, ids, pos, d_count, delta, emit_count, sums, out_info + 1);

@@ -67,7 +67,7 @@ struct NbodyHandle {
     void* d_tree_ws = nullptr;   // device-build workspace (keys, sort buffers, scans)
     void* d_tree_cat = nullptr;  // sharded device build: concatenated positions, own-order list
     size_t tree_ws_cap = 0;      // bodies it is sized for
-    int* d_tree_info = nullptr;  // [2] node count, flags
+    int* d_tree_info = nullptr;  // [3] node count, flags, bodies in the tree
     int* h_tree_info = nullptr;  // pinned
     bool tree_on_device = false; // the last tree was built on the device (export copies it back)
     int* d_split = nullptr;      // [33 + 32 + 32*192] ints: first[], n_anc[], anc[][192]
@@ -556,8 +556,8 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
         h->tree_ws_cap = n_cap;
     }
     if (!h->d_tree_info) {
-        HIP_TRY(h, hipMalloc(&h->d_tree_info, 2 * sizeof(int)));
-        HIP_TRY(h, hipHostMalloc(&h->h_tree_info, 2 * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc(&h->d_tree_info, 4 * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(&h->h_tree_info, 4 * sizeof(int), hipHostMallocDefault));
     }
     const size_t tot_upper = total_upper(h);
     // a Plummer sphere gives ~1.5 nodes per body; 4 per body + the count read-back below catch the rest
@@ -579,9 +579,11 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
                                        &work) != 0)
             return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipMemcpyAsync(h->h_tree_info, h->d_tree_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int) * sh.n_seg, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_tree_info, h->d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (sharded)
+            HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int) * sh.n_seg, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (!sharded) h->h_counts[0] = h->h_tree_info[2];  // one shard: the tree's body count is the live count
         if (!(h->h_tree_info[1] & 2)) break;
         rc = ensure_tree_dev(h, size_t(h->h_tree_info[0]) + 64, tot_upper);  // more nodes than allowed for: grow, rebuild
         if (rc) return rc;
