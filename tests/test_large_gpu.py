@@ -89,3 +89,41 @@ def test_barnes_hut_four_million_bodies_host_and_device_tree(gpu, orc):
     assert sdev.tree_nodes == s.tree_nodes
     dev_err = np.abs(dev.astype(np.float64) - host).max(axis=1) / np.abs(host).max()
     assert np.quantile(dev_err, 0.999) < 1e-5 and dev_err.max() < 1e-2, (np.quantile(dev_err, 0.999), dev_err.max())
+
+
+def test_brute_force_one_million_bodies_in_eight_shards(gpu, orc):
+    """configs[3] as written: 1 048 576 bodies sharded 8 ways (131 072 per shard), every pair between
+    shards evaluated once -- eight handles on this one device play the eight GPUs, both exchanges done
+    by device-to-device copies (the nbody_debug_* hooks; the RCCL calls themselves need eight GPUs).
+    One step against the single-handle run of the same bodies: the same pairs in a different
+    association order, and against f64 rows of the oracle on a sample."""
+    nb = gpu
+    n, G = 1 << 20, 8
+    sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
+    st = nb.Settings(**sd)
+    ics = nb.plummer(n, seed=12)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as one:
+        one.settings = st
+        one.init()
+        one.step()
+        ref = one.get_points()
+    sims = [nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST, rank=r, world_size=G, capacity=n) for r in range(G)]
+    for s in sims:
+        s.settings = st
+        s.init()
+    nb.sharded_step(sims)
+    got = np.concatenate([s.get_points() for s in sims])
+    assert sum(len(s) for s in sims) == n == len(ref)
+    for s in sims:
+        s.close()
+    assert np.isfinite(got["acceleration"]).all()
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
+    assert rel_err(got["velocity"], ref["velocity"]) < 1e-6
+    # f64 oracle rows for a few bodies of different shards (accelerations belong to the half-drifted positions)
+    half = orc.to_f64(ics)
+    orc.pre_force(half, float(np.float32(sd["dt"])))
+    sd64 = dict(sd, g_soft=float(np.float32(sd["g_soft"])))
+    for lo, hi in [(0, 16), (131072 * 3 - 8, 131072 * 3 + 8), (n - 16, n)]:
+        orc.bf_update_forces_range(half, sd64, lo, hi, threads=16)
+        assert rel_err(got["acceleration"][lo:hi], half["acceleration"][lo:hi]) < 3e-5
