@@ -127,3 +127,41 @@ def test_brute_force_one_million_bodies_in_eight_shards(gpu, orc):
     for lo, hi in [(0, 16), (131072 * 3 - 8, 131072 * 3 + 8), (n - 16, n)]:
         orc.bf_update_forces_range(half, sd64, lo, hi, threads=16)
         assert rel_err(got["acceleration"][lo:hi], half["acceleration"][lo:hi]) < 3e-5
+
+
+def test_barnes_hut_four_million_bodies_in_eight_shards(gpu):
+    """configs[4]'s body count sharded 8 ways (option A of SURVEY section 8e: every GPU builds the global
+    tree from the gathered positions -- here on the device -- and walks it for its own 524 288 bodies;
+    eight handles on one device, exchange by device-to-device copies).  Same tree, same per-body walk:
+    one step equals the single-handle run bit for bit and the node counts add up exactly."""
+    import ctypes
+    nb = gpu
+    n, G = 1 << 22, 8
+    st = nb.Settings(1.0, 1e-2, 1e-3, 0.25)
+    ics = nb.plummer(n, seed=13)
+    split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    split.value = 2   # (the default follows the number of own bodies; the sum order of the segments must match)
+    try:
+        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as one:
+            one.settings = st
+            one.init()
+            one.step()
+            ref = one.get_points()
+            s1 = one.stats()
+        sims = [nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, rank=r, world_size=G, capacity=n,
+                              tree_build=nb.TREE_DEVICE) for r in range(G)]
+        for s in sims:
+            s.settings = st
+            s.init()
+        nb.sharded_step(sims)
+        got = np.concatenate([s.get_points() for s in sims])
+        stats = [s.stats() for s in sims]
+        for s in sims:
+            s.close()
+    finally:
+        split.value = 0
+    assert len(got) == len(ref) == n
+    for f in ("position", "velocity", "acceleration", "mass"):
+        assert np.array_equal(got[f], ref[f]), f
+    assert sum(s.interactions for s in stats) == s1.interactions and sum(s.node_visits for s in stats) == s1.node_visits
+    assert all(s.tree_nodes == s1.tree_nodes for s in stats)
