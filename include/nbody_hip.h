@@ -61,13 +61,18 @@ enum { NBODY_TREE_HOST = 0,    /* host, every step (north_star; barnes_hut.rs:14
                                    by a few parts in 1e4; single shard, <= 21 levels (else falls back to host) */
 
 /* Barnes-Hut leaf semantics */
-enum { NBODY_LEAF_REFERENCE = 0 }; /* src/manual: a leaf failing the opening test contributes 0 */
+enum {
+    NBODY_LEAF_REFERENCE = 0, /* src/manual/barnes_hut.rs:185-203: a leaf failing the opening test contributes 0 */
+    NBODY_LEAF_DIRECT = 1     /* the walk of src/llm/barnes_hut.rs:915-997 on the same tree: a node closer than
+                                 r2 < 1e-10 is skipped whole (how a body skips itself), a leaf failing the opening
+                                 test is evaluated directly; force = d * (g*mass * (1/sqrt(r2+eps2))^3) */
+};
 
 typedef struct NbodyConfig {
     uint32_t struct_size;  /* = sizeof(NbodyConfig) */
     int32_t method;        /* NBODY_BRUTE_FORCE | NBODY_BARNES_HUT */
     int32_t math_mode;     /* NBODY_MATH_STRICT | NBODY_MATH_FAST */
-    int32_t leaf_mode;     /* NBODY_LEAF_REFERENCE */
+    int32_t leaf_mode;     /* NBODY_LEAF_REFERENCE (default) | NBODY_LEAF_DIRECT; Barnes-Hut only */
     int32_t device;        /* HIP device ordinal; -1 = LOCAL_RANK env or 0 */
     int32_t rank;          /* this process's shard, 0 <= rank < world_size */
     int32_t world_size;    /* number of shards (one process per GPU); 1 = single GPU */

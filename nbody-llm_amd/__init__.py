@@ -37,7 +37,8 @@ NBODY_ERR_COMM = -5
 NBODY_ERR_NO_DEVICE = -6
 BRUTE_FORCE, BARNES_HUT = 0, 1
 STRICT, FAST = 0, 1
-LEAF_REFERENCE = 0
+LEAF_REFERENCE = 0   # src/manual: a leaf failing the opening test contributes nothing
+LEAF_DIRECT = 1      # the src/llm walk on the same tree: such a leaf is evaluated directly
 TREE_HOST, TREE_DEVICE = 0, 1
 COMM_ID_BYTES = 128
 
@@ -198,13 +199,14 @@ class Simulation:
 
     def __init__(self, points: np.ndarray, center=(0.0, 0.0, 0.0), width: float = 1.0, *, method: int = BRUTE_FORCE,
                  math_mode: int = STRICT, capacity: int | None = None, device: int = -1, rank: int = 0,
-                 world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_HOST, _handle=None):
+                 world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_HOST, leaf_mode: int = LEAF_REFERENCE,
+                 _handle=None):
         self._h = _H()
         if _handle is not None:
             self._h = _handle
             return
         points = np.ascontiguousarray(points, dtype=PARTICLE_DTYPE)
-        cfg = NbodyConfig(C.sizeof(NbodyConfig), method, math_mode, LEAF_REFERENCE, device, rank, world_size,
+        cfg = NbodyConfig(C.sizeof(NbodyConfig), method, math_mode, leaf_mode, device, rank, world_size,
                           host_threads, int(capacity if capacity is not None else max(1, points.shape[0])), tree_build, 0)
         rc = lib.nbody_create(C.byref(cfg), C.byref(self._h))
         if rc:

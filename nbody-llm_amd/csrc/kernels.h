@@ -129,7 +129,7 @@ void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_
                            int* n_anc, int* anc, int max_anc);
 
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
-                    int fast_math, unsigned long long* counters /* [2]: accepted, visited */);
+                    int fast_math, unsigned long long* counters /* [2]: accepted, visited */, int leaf_direct = 0);
 
 // diagnostics: f64 energies of the own segment against all segments; out = {KE, PE_pairs_sum}
 void launch_energy(hipStream_t s, const Shard& sh, int n_upper, double g_soft2, double* out2);

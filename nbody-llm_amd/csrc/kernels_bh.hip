@@ -43,6 +43,7 @@ struct WalkSplit {
 };
 constexpr int kMaxAnc = 192;
 
+template <bool DIRECT = false>
 __device__ __forceinline__ int walk_entry(const NodeDev* __restrict__ nodes, const WalkSplit& sp, int seg,
                                           const float4 p, float theta2) {
     const int s0 = sp.first[seg];
@@ -53,12 +54,14 @@ __device__ __forceinline__ int walk_entry(const NodeDev* __restrict__ nodes, con
         const float4 B = nodes[j].b;
         const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;
         const float r2 = (rx * rx + ry * ry) + rz * rz;
+        if (DIRECT && r2 < 1e-10f) return __float_as_int(B.y);  // NBODY_LEAF_DIRECT: skipped whole
         if (B.x < theta2 * r2) return __float_as_int(B.y);  // accepted: the walk resumes after its subtree
     }
     return s0;  // every ancestor was opened: the walk arrives at first[seg] itself
 }
 
-template <bool FAST>
+// DIRECT = NBODY_LEAF_DIRECT: the walk of src/llm/barnes_hut.rs:915-997 on the same tree (see nbody_hip.h)
+template <bool FAST, bool DIRECT = false>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restrict__ nodes, int n_nodes,
                                                         const int* __restrict__ order, int n_order,
                                                         const float4* __restrict__ own_pos, float4* __restrict__ acc,
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
         const int b = order[t];
         const float4 p = own_pos[b];
         float ax = 0.f, ay = 0.f, az = 0.f;
-        int i = walk_entry(nodes, split, seg, p, theta2);  // first node >= s0 this body's walk visits
+        int i = walk_entry<DIRECT>(nodes, split, seg, p, theta2);  // first node >= s0 this body's walk visits
         while (i < s1) {
             const float4 A = nodes[i].a;
             const float4 B = nodes[i].b;
@@ -83,6 +86,27 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
             const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
             const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
             ++n_vis;
+            if (DIRECT) {
+                const int skip = __float_as_int(B.y);
+                if (r2 < 1e-10f) { i = skip; continue; }                        // llm :933-935 (the body's own leaf: r2 = 0)
+                if (B.x < theta2 * r2 || skip == i + 1) {                       // llm :938 accepted cell, :958-972 leaf
+                    float k;
+                    if (FAST) {
+                        const float rinv = __builtin_amdgcn_rsqf(r2 + eps2);
+                        k = (g * A.w) * ((rinv * rinv) * rinv);
+                    } else {
+                        const float inv_r = 1.0f / __builtin_sqrtf(r2 + eps2);  // llm :942
+                        const float inv_r3 = inv_r * inv_r * inv_r;             // llm :944
+                        k = g * A.w * inv_r3;                                   // llm :947
+                    }
+                    ax += rx * k; ay += ry * k; az += rz * k;                   // llm :950-952: one running sum
+                    ++n_acc;
+                    i = skip;
+                } else {
+                    i = i + 1;
+                }
+                continue;
+            }
             if (B.x < theta2 * r2) {                                            // :192
                 float k;
                 if (FAST) {
@@ -282,16 +306,18 @@ __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ pl
 }
 
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
-                    int fast_math, unsigned long long* counters) {
+                    int fast_math, unsigned long long* counters, int leaf_direct) {
     if (t.n_order <= 0) return;
     WalkSplit sp;
     sp.n_seg = t.n_split; sp.first = t.split_first; sp.anc = t.split_anc; sp.n_anc = t.split_n_anc;
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
     dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
-    if (nbody_bh_walk_variant == 2) grid.x = (2 * t.n_order + kWalkBlock - 1) / kWalkBlock;
+    const int variant = leaf_direct ? 0 : nbody_bh_walk_variant;  // the alternative walks know the reference leaf rule only
+    if (variant == 2) grid.x = (2 * t.n_order + kWalkBlock - 1) / kWalkBlock;
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
-    if (nbody_bh_walk_variant == 1) { if (fast_math) WALK(k_bh_walk_wave, true); else WALK(k_bh_walk_wave, false); }
-    else if (nbody_bh_walk_variant == 2) { if (fast_math) WALK(k_bh_walk_pair, true); else WALK(k_bh_walk_pair, false); }
+    if (variant == 1) { if (fast_math) WALK(k_bh_walk_wave, true); else WALK(k_bh_walk_wave, false); }
+    else if (variant == 2) { if (fast_math) WALK(k_bh_walk_pair, true); else WALK(k_bh_walk_pair, false); }
+    else if (leaf_direct) { if (fast_math) WALK(k_bh_walk, true, true); else WALK(k_bh_walk, false, true); }
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
     if (t.n_split > 1)

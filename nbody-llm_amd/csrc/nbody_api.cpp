@@ -534,7 +534,7 @@ int bh_forces(NbodyHandle* h) {
     {
         ForceTimer t(h);
         nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
-                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters);
+                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT);
     }
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
@@ -639,7 +639,7 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     {
         ForceTimer t(h);
         nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
-                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters);
+                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT);
     }
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
@@ -774,7 +774,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (cfg->struct_size != sizeof(NbodyConfig)) return fail(nullptr, NBODY_ERR_INVALID, "NbodyConfig.struct_size mismatch");
     if (cfg->method != NBODY_BRUTE_FORCE && cfg->method != NBODY_BARNES_HUT) return fail(nullptr, NBODY_ERR_INVALID, "unknown method");
     if (cfg->math_mode != NBODY_MATH_STRICT && cfg->math_mode != NBODY_MATH_FAST) return fail(nullptr, NBODY_ERR_INVALID, "unknown math_mode");
-    if (cfg->leaf_mode != NBODY_LEAF_REFERENCE) return fail(nullptr, NBODY_ERR_INVALID, "unknown leaf_mode");
+    if (cfg->leaf_mode != NBODY_LEAF_REFERENCE && cfg->leaf_mode != NBODY_LEAF_DIRECT) return fail(nullptr, NBODY_ERR_INVALID, "unknown leaf_mode");
     if (cfg->tree_build != NBODY_TREE_HOST && cfg->tree_build != NBODY_TREE_DEVICE) return fail(nullptr, NBODY_ERR_INVALID, "unknown tree_build");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, NBODY_ERR_INVALID, "bad rank/world_size");
     if (cfg->capacity == 0 || cfg->capacity > (1ull << 30)) return fail(nullptr, NBODY_ERR_INVALID, "capacity must be in [1, 2^30]");

@@ -86,12 +86,13 @@ public:
 
 protected:
     Simulation(int method, const std::vector<PointParticle>& points, const Bounds& bounds, int math_mode,
-               size_t capacity, int host_threads, int tree_build = NBODY_TREE_HOST) : bounds_(bounds) {
+               size_t capacity, int host_threads, int tree_build = NBODY_TREE_HOST,
+               int leaf_mode = NBODY_LEAF_REFERENCE) : bounds_(bounds) {
         NbodyConfig cfg{};
         cfg.struct_size = sizeof(cfg);
         cfg.method = method;
         cfg.math_mode = math_mode;
-        cfg.leaf_mode = NBODY_LEAF_REFERENCE;
+        cfg.leaf_mode = leaf_mode;
         cfg.device = -1;
         cfg.rank = 0;
         cfg.world_size = 1;
@@ -143,8 +144,8 @@ class BarnesHutSimulation : public Simulation {
 public:
     BarnesHutSimulation(const std::vector<PointParticle>& points, const Bounds& bounds,
                         int math_mode = NBODY_MATH_FAST, size_t capacity = 0, int host_threads = 0,
-                        int tree_build = NBODY_TREE_HOST)
-        : Simulation(NBODY_BARNES_HUT, points, bounds, math_mode, capacity, host_threads, tree_build) {}
+                        int tree_build = NBODY_TREE_HOST, int leaf_mode = NBODY_LEAF_REFERENCE)
+        : Simulation(NBODY_BARNES_HUT, points, bounds, math_mode, capacity, host_threads, tree_build, leaf_mode) {}
     std::unique_ptr<BarnesHutSimulation> clone() const {
         return std::unique_ptr<BarnesHutSimulation>(new BarnesHutSimulation(clone_handle(), *this));
     }

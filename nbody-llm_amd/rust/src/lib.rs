@@ -95,7 +95,7 @@ impl<const METHOD: i32> HipSimulation<METHOD> {
             struct_size: std::mem::size_of::<NbodyConfig>() as u32,
             method: METHOD,
             math_mode: NBODY_MATH_FAST,
-            leaf_mode: 0,
+            leaf_mode: 0, // NBODY_LEAF_REFERENCE (src/manual); 1 = NBODY_LEAF_DIRECT (the src/llm walk)
             device: -1,
             rank: 0,
             world_size: 1,

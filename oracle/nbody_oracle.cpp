@@ -19,6 +19,7 @@
 //   src/manual/barnes_hut.rs:143-183 build_tree                   -> build_tree
 //   src/manual/barnes_hut.rs:185-203 calc_force                   -> calc_force
 //   src/manual/barnes_hut.rs:250-271 update_forces / step_by      -> bh_update_forces / bh_step_by
+//   src/llm/barnes_hut.rs:915-997    calc_force_3d (leaf semantics) -> calc_force_direct (leaf_mode 1)
 //
 // nalgebra 0.33.2 (Cargo.lock) is not in the container.  Its published algorithm for a
 // 3-vector `norm_squared()` is dotc(self,self) with the fixed-size-3 special case
@@ -290,6 +291,37 @@ void calc_force(const OrthNode<F>& node, const F pos[3], const Settings<F>& s, F
     }
 }
 
+// The OTHER leaf semantics found in the reference ("leaf-mode decision"): the walk
+// of src/llm/barnes_hut.rs:915-997 (calc_force_3d) applied to the src/manual tree.  Explicit stack
+// there, children pushed in reverse so they pop in orthant order = this recursion's order; ONE running
+// sum (force_x += ...); a node closer than r2 < 1e-10 is skipped whole (:933-935; that is how a body
+// skips its own leaf); an accepted cell adds g*mass * (1/sqrt(r2+eps2))^3 (:938-954); a leaf that fails
+// the opening test is evaluated directly with the same formula unless it is the body itself (:958-972).
+template <class F>
+void calc_force_direct(const OrthNode<F>& node, const Body<F>* self, const F pos[3], const Settings<F>& s, F acc[3],
+                       WalkCount& cnt) {
+    cnt.visited++;
+    const F dx = node.com[0] - pos[0], dy = node.com[1] - pos[1], dz = node.com[2] - pos[2];
+    const F r2 = dx * dx + dy * dy + dz * dz;
+    if (r2 < F(1e-10)) return;
+    const F g_soft2 = s.g_soft * s.g_soft;
+    bool is_leaf = true;
+    for (int i = 0; i < 8; ++i) if (node.children[i]) is_leaf = false;
+    const bool accept = node.bounds.width * node.bounds.width < s.theta2 * r2;
+    if (accept || is_leaf) {
+        if (!accept && (node.leaf_body == self || !node.leaf_body)) return;   // own leaf / empty node
+        const F r_soft2 = r2 + g_soft2;
+        const F inv_r = F(1) / std::sqrt(r_soft2);
+        const F inv_r3 = inv_r * inv_r * inv_r;
+        const F fm = s.g * node.mass * inv_r3;
+        acc[0] += dx * fm; acc[1] += dy * fm; acc[2] += dz * fm;
+        cnt.accepted++;
+        return;
+    }
+    for (int i = 0; i < 8; ++i)
+        if (node.children[i]) calc_force_direct(*node.children[i], self, pos, s, acc, cnt);
+}
+
 template <class F>
 std::unique_ptr<OrthNode<F>> build_root(const Body<F>* p, size_t n, const Box3<F>& box, int threads, bool* too_deep) {
     std::vector<const Body<F>*> refs(n);
@@ -299,15 +331,16 @@ std::unique_ptr<OrthNode<F>> build_root(const Body<F>* p, size_t n, const Box3<F
 
 template <class F>
 int bh_update_forces(Body<F>* p, size_t n, const Settings<F>& s, const Box3<F>& box, int threads,
-                     uint64_t* accepted, uint64_t* visited) {  // barnes_hut.rs:250-263
+                     uint64_t* accepted, uint64_t* visited, int leaf_mode = 0) {  // barnes_hut.rs:250-263
     bool too_deep = false;
     auto root = build_root(p, n, box, threads, &too_deep);
     if (too_deep) return -2;
     std::vector<WalkCount> counts(std::max(1, threads));
     auto work = [&](int t, size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; ++k) {
-            F f[3];
-            calc_force(*root, p[k].pos, s, f, counts[t]);
+            F f[3] = {F(0), F(0), F(0)};
+            if (leaf_mode == 1) calc_force_direct(*root, &p[k], p[k].pos, s, f, counts[t]);
+            else calc_force(*root, p[k].pos, s, f, counts[t]);
             p[k].acc[0] = f[0]; p[k].acc[1] = f[1]; p[k].acc[2] = f[2];   // overwrite, :260
         }
     };
@@ -384,10 +417,10 @@ void energy(const Body<F>* p, size_t n, double g, double g_soft, int threads, do
 
 template <class F>
 size_t bh_step_by(Body<F>* p, size_t n, const Settings<F>& s, const Box3<F>& box, F dt, int threads,
-                  uint64_t* accepted, uint64_t* visited, int* rc) {  // barnes_hut.rs:265-271
+                  uint64_t* accepted, uint64_t* visited, int* rc, int leaf_mode = 0) {  // barnes_hut.rs:265-271
     pre_force(p, n, dt);
     n = retain_in_bounds(p, n, box);
-    *rc = bh_update_forces(p, n, s, box, threads, accepted, visited);
+    *rc = bh_update_forces(p, n, s, box, threads, accepted, visited, leaf_mode);
     after_force(p, n, dt);
     return n;
 }
@@ -423,6 +456,22 @@ size_t bh_step_by(Body<F>* p, size_t n, const Settings<F>& s, const Box3<F>& box
                                                  int threads, uint64_t* accepted, uint64_t* visited) {         \
         return bh_update_forces((Body<F>*)aos, n, Settings<F>{s[0], s[1], s[2], s[3]}, Box3<F>::make(c, w),    \
                                 threads, accepted, visited);                                                   \
+    }                                                                                                          \
+    /* leaf_mode 1: the src/llm walk (calc_force_direct) on the same tree */                                    \
+    extern "C" int oracle_bh_update_forces_mode_##SFX(F* aos, size_t n, const F s[4], const F c[3], F w,       \
+                                                      int threads, uint64_t* accepted, uint64_t* visited,      \
+                                                      int leaf_mode) {                                         \
+        return bh_update_forces((Body<F>*)aos, n, Settings<F>{s[0], s[1], s[2], s[3]}, Box3<F>::make(c, w),    \
+                                threads, accepted, visited, leaf_mode);                                        \
+    }                                                                                                          \
+    extern "C" size_t oracle_bh_step_by_mode_##SFX(F* aos, size_t n, const F s[4], const F c[3], F w, F dt,    \
+                                                   int threads, uint64_t* accepted, uint64_t* visited,         \
+                                                   int* rc, int leaf_mode) {                                   \
+        int r = 0;                                                                                             \
+        size_t m = bh_step_by((Body<F>*)aos, n, Settings<F>{s[0], s[1], s[2], s[3]}, Box3<F>::make(c, w), dt,  \
+                              threads, accepted, visited, &r, leaf_mode);                                      \
+        if (rc) *rc = r;                                                                                       \
+        return m;                                                                                              \
     }                                                                                                          \
     extern "C" size_t oracle_bh_step_by_##SFX(F* aos, size_t n, const F s[4], const F c[3], F w, F dt,         \
                                               int threads, uint64_t* accepted, uint64_t* visited, int* rc) {   \

@@ -117,27 +117,28 @@ def bf_step_by(a, settings, center, width, dt) -> np.ndarray:
     return a[:n]
 
 
-def bh_update_forces(a, settings, center, width, threads=1):
-    """Returns (accepted, visited) node counts."""
+def bh_update_forces(a, settings, center, width, threads=1, leaf_mode=0):
+    """Returns (accepted, visited) node counts.  leaf_mode 0: src/manual (a leaf failing the opening test
+    contributes nothing); 1: the src/llm walk on the same tree (such a leaf is evaluated directly)."""
     s, ct, _ = _sfx(a)
-    fn = getattr(lib(), f"oracle_bh_update_forces_{s}")
+    fn = getattr(lib(), f"oracle_bh_update_forces_mode_{s}")
     fn.restype = C.c_int
     acc, vis = C.c_uint64(0), C.c_uint64(0)
     rc = fn(C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), _settings(ct, settings), _arr(ct, center), ct(width),
-            C.c_int(threads), C.byref(acc), C.byref(vis))
+            C.c_int(threads), C.byref(acc), C.byref(vis), C.c_int(leaf_mode))
     if rc:
         raise RuntimeError(f"oracle_bh_update_forces rc={rc}")
     return acc.value, vis.value
 
 
-def bh_step_by(a, settings, center, width, dt, threads=1):
+def bh_step_by(a, settings, center, width, dt, threads=1, leaf_mode=0):
     """One BarnesHutSimulation::step_by; returns (array view, accepted, visited)."""
     s, ct, _ = _sfx(a)
-    fn = getattr(lib(), f"oracle_bh_step_by_{s}")
+    fn = getattr(lib(), f"oracle_bh_step_by_mode_{s}")
     fn.restype = C.c_size_t
     acc, vis, rc = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
     n = fn(C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), _settings(ct, settings), _arr(ct, center), ct(width), ct(dt),
-           C.c_int(threads), C.byref(acc), C.byref(vis), C.byref(rc))
+           C.c_int(threads), C.byref(acc), C.byref(vis), C.byref(rc), C.c_int(leaf_mode))
     if rc.value:
         raise RuntimeError(f"oracle_bh_step_by rc={rc.value}")
     return a[:n], acc.value, vis.value

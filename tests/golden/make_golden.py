@@ -29,8 +29,8 @@ def run(kind, n, ftype, steps, st):
     for _ in range(steps):
         if kind == "bf":
             a = orc.bf_step_by(a, st, CENTER, WIDTH, st["dt"])
-        else:
-            a, acc, vis = orc.bh_step_by(a, st, CENTER, WIDTH, st["dt"], threads=1)
+        else:   # "bh": src/manual leaf rule; "bhd": the src/llm walk on the same tree (leaf_mode 1)
+            a, acc, vis = orc.bh_step_by(a, st, CENTER, WIDTH, st["dt"], threads=1, leaf_mode=1 if kind == "bhd" else 0)
             counts.append((acc, vis))
     return ics, a, np.array(counts, dtype=np.uint64)
 
@@ -42,7 +42,11 @@ def main():
             cases.append(("bf", n, ftype, dict(g=1.0, g_soft=0.0, dt=1e-3, theta2=0.5)))
             cases.append(("bh", n, ftype, dict(g=1.0, g_soft=0.0, dt=1e-3, theta2=0.25)))
             cases.append(("bh", n, ftype, dict(g=1.0, g_soft=0.0, dt=1e-3, theta2=0.5)))
+            cases.append(("bhd", n, ftype, dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=0.25)))
+    only = sys.argv[1] if len(sys.argv) > 1 else None   # e.g. "bhd": write only that kind
     for kind, n, ftype, st in cases:
+        if only and kind != only:
+            continue
         ics, out, counts = run(kind, n, ftype, 10, st)
         name = f"{kind}_n{n}_{ftype}_t{int(st['theta2'] * 100):03d}.npz"
         np.savez_compressed(os.path.join(OUT, name), kind=kind, n=n, ftype=ftype, steps=10,

@@ -1,0 +1,132 @@
+"""NBODY_LEAF_DIRECT -- the leaf semantics of src/llm/barnes_hut.rs:915-997 on the src/manual tree
+(leaf-mode decision) -- through the C ABI against the oracle's restatement of that
+walk: node counts exact, accelerations to rounding (strict: the same formula with IEEE sqrt and
+divide; fast: v_rsq_f32), over steps, with bodies leaving, with the device-side tree, sharded."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BOX = ((0.0, 0.0, 0.0), 64.0)
+
+
+@pytest.mark.parametrize("math", ["strict", "fast"])
+@pytest.mark.parametrize("n,theta2", [(1, 0.25), (2, 0.25), (9, 1.0), (1000, 0.25), (5000, 0.5), (20000, 0.25)])
+def test_direct_leaf_mode_counts_and_accelerations(gpu, orc, n, theta2, math):
+    nb = gpu
+    sd = dict(g=1.25, g_soft=0.02, dt=1e-3, theta2=theta2)
+    ics = nb.plummer(n, seed=40 + n)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4, leaf_mode=1)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT if math == "strict" else nb.FAST,
+                       leaf_mode=nb.LEAF_DIRECT) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    if n > 1:   # (the walk adds the partial sums of its node-range segments: rounding differs from the one running sum)
+        assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    else:
+        assert not got["acceleration"].any()
+
+
+@pytest.mark.parametrize("n", [2, 777, 20000])
+def test_direct_leaf_mode_strict_unsplit_walk_is_bit_exact(gpu, orc, n):
+    """The src/llm walk keeps ONE running sum in visit order; so does a lane of k_bh_walk.  With the
+    node range unsplit (one segment) and strict math the accelerations equal the oracle's bit for bit."""
+    import ctypes
+    nb = gpu
+    sd = dict(g=1.25, g_soft=0.02, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(n, seed=41 + n)
+    ref = ics.copy().astype(orc.P32)
+    orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4, leaf_mode=1)
+    split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    split.value = 1
+    try:
+        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT, leaf_mode=nb.LEAF_DIRECT) as sim:
+            sim.settings = nb.Settings(**sd)
+            sim.update_forces()
+            got = sim.get_points()
+    finally:
+        split.value = 0
+    assert np.array_equal(got["acceleration"].view(np.uint32), ref["acceleration"].view(np.uint32))
+
+
+def test_direct_leaf_mode_is_accurate(gpu, orc):
+    """The point of the mode: with the near field evaluated the walk approximates the direct sum
+    (median error < 1 % at theta = 0.5; the src/manual rule gives ~10-17 % on the same tree)."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=0.25)
+    ics = nb.plummer(8000, seed=44)
+    exact = orc.to_f64(ics)
+    orc.bf_update_forces_rows(exact, dict(sd, g_soft=float(np.float32(sd["g_soft"]))), threads=8)
+    errs = {}
+    for mode in (nb.LEAF_REFERENCE, nb.LEAF_DIRECT):
+        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, leaf_mode=mode) as sim:
+            sim.settings = nb.Settings(**sd)
+            sim.update_forces()
+            a = sim.get_points()["acceleration"].astype(np.float64)
+        errs[mode] = np.median(np.linalg.norm(a - exact["acceleration"], axis=1) / np.linalg.norm(exact["acceleration"], axis=1))
+    assert errs[nb.LEAF_DIRECT] < 1e-2 < errs[nb.LEAF_REFERENCE]
+
+
+@pytest.mark.parametrize("tree", ["host", "device"])
+def test_direct_leaf_mode_steps_with_escapes(gpu, orc, tree):
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 3.0)
+    sd = dict(g=1.0, g_soft=0.05, dt=1e-2, theta2=0.25)
+    ics = nb.plummer(3000, seed=45)
+    ref = ics.copy().astype(orc.P32)
+    tot_a = tot_v = 0
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.STRICT, leaf_mode=nb.LEAF_DIRECT,
+                       tree_build=nb.TREE_DEVICE if tree == "device" else nb.TREE_HOST) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.init()
+        for _ in range(6):
+            sim.step()
+            ref, a, v = orc.bh_step_by(ref, sd, box[0], box[1], sd["dt"], threads=4, leaf_mode=1)
+            tot_a += a
+            tot_v += v
+        got = sim.get_points()
+        s = sim.stats()
+    assert len(ref) < 3000 and len(got) == len(ref)
+    if tree == "host":
+        assert (s.interactions, s.node_visits) == (tot_a, tot_v)
+    else:   # f64 prefix-sum centres of mass: an opening test on the edge can flip (test_bh_device_tree_gpu.py)
+        assert abs(int(s.interactions) - tot_a) <= 1e-3 * tot_a and abs(int(s.node_visits) - tot_v) <= 1e-3 * tot_v
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-5
+    assert rel_err(got["velocity"], ref["velocity"]) < 1e-4
+
+
+def test_direct_leaf_mode_sharded_equals_single(gpu, orc):
+    nb = gpu
+    st = nb.Settings(1.0, 0.01, 1e-3, 0.25)
+    ics = nb.plummer(6000, seed=46)
+    sims = [nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT, leaf_mode=nb.LEAF_DIRECT, rank=r, world_size=3,
+                          capacity=len(ics)) for r in range(3)]
+    for s in sims:
+        s.settings = st
+        s.init()
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT, leaf_mode=nb.LEAF_DIRECT) as one:
+        one.settings = st
+        one.init()
+        for _ in range(3):
+            nb.sharded_step(sims)
+            one.step()
+        ref = one.get_points()
+        s1 = one.stats()
+    got = np.concatenate([s.get_points() for s in sims])
+    stats = [s.stats() for s in sims]
+    for s in sims:
+        s.close()
+    assert sum(s.interactions for s in stats) == s1.interactions and sum(s.node_visits for s in stats) == s1.node_visits
+    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-6
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
+
+
+def test_unknown_leaf_mode_is_refused(gpu):
+    nb = gpu
+    with pytest.raises(Exception):
+        nb.Simulation(nb.plummer(10), *BOX, method=nb.BARNES_HUT, leaf_mode=7)

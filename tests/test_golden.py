@@ -1,7 +1,8 @@
 """Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the
 oracle; the reference itself has none -- "parity unpinned").  CPU: the oracle still reproduces
 them bit for bit and f32 tracks f64.  GPU: the HIP path reproduces the f32 vectors (brute force
-strict: bit-exact; Barnes-Hut: counts exact, state to rounding)."""
+strict: bit-exact; Barnes-Hut, both leaf rules ("bh" src/manual, "bhd" the src/llm walk): counts exact,
+state to rounding)."""
 import glob
 import os
 
@@ -18,7 +19,7 @@ def load(path):
 
 
 def test_fixture_set_is_complete():
-    assert len(GOLDEN) == 12
+    assert len(GOLDEN) == 16
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=os.path.basename)
@@ -30,7 +31,7 @@ def test_oracle_reproduces_golden(orc, path):
         if str(z["kind"]) == "bf":
             a = orc.bf_step_by(a, st, center, width, st["dt"])
         else:
-            a, acc, vis = orc.bh_step_by(a, st, center, width, st["dt"], threads=2)
+            a, acc, vis = orc.bh_step_by(a, st, center, width, st["dt"], threads=2, leaf_mode=1 if str(z["kind"]) == "bhd" else 0)
             counts.append((acc, vis))
     for f in ("position", "velocity", "acceleration", "mass"):
         assert np.array_equal(a[f], z[f]), f
@@ -55,7 +56,8 @@ def test_hip_path_reproduces_golden(gpu, path):
     z, st, center, width = load(path)
     kind = str(z["kind"])
     method = nb.BRUTE_FORCE if kind == "bf" else nb.BARNES_HUT
-    with nb.Simulation(z["ics"], center, width, method=method, math_mode=nb.STRICT) as sim:
+    with nb.Simulation(z["ics"], center, width, method=method, math_mode=nb.STRICT,
+                       leaf_mode=nb.LEAF_DIRECT if kind == "bhd" else nb.LEAF_REFERENCE) as sim:
         sim.settings = nb.Settings(**st)
         sim.init()
         sim.steps(int(z["steps"]))
