@@ -102,6 +102,10 @@ struct TreeDev {
     const int* split_n_anc = nullptr;   // [n_split]
     float4* split_planes = nullptr;     // [n_split][split_stride]
     size_t split_stride = 0;
+    // strict math, reference leaf rule: per-lane stack of open cells {partial sum, end index} for the
+    // reference's nested sums (k_bh_walk_nested); [NBODY_MAX_TREE_DEPTH + 1][nested_stride]
+    float4* nested_stack = nullptr;
+    size_t nested_stride = 0;
 };
 // device-side octree build (kernels_tree.hip)
 struct TreeDevWork {  // arrays of the last build the split-point kernel needs

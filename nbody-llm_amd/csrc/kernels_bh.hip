@@ -286,6 +286,85 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_pair(const NodeDev* __re
     }
 }
 
+// Strict math, reference leaf rule: the reference's NESTED sums (barnes_hut.rs:196-202: every opened
+// cell folds its children's results left to right from zero and hands the sum up).  One running sum
+// per lane reproduces the visits but not that association; this kernel keeps, per lane, the open
+// cells' partial sums: the innermost in registers, the others on a stack in global memory
+// ([depth][lane], touched only when a cell is opened or finished).  Every add the reference performs
+// is performed, in its order -- including `acc += 0` for a leaf that fails the test -- so the
+// accelerations equal the oracle's bit for bit.  The node range is not split (the association would
+// change); this is the parity path, the fast path is k_bh_walk.
+__global__ __launch_bounds__(kWalkBlock) void k_bh_walk_nested(const NodeDev* __restrict__ nodes, int n_nodes,
+                                                               const int* __restrict__ order, int n_order,
+                                                               const float4* __restrict__ own_pos,
+                                                               float4* __restrict__ acc, float g, float eps2,
+                                                               float theta2, unsigned long long* __restrict__ counters,
+                                                               float4* __restrict__ stack, size_t stack_stride) {
+    const int t = blockIdx.x * kWalkBlock + threadIdx.x;
+    unsigned int n_acc = 0, n_vis = 0;
+    if (t < n_order) {
+        const int b = order[t];
+        const float4 p = own_pos[b];
+        float sx = 0.f, sy = 0.f, sz = 0.f;   // the innermost open cell's running sum
+        int end = 0;                          // ... and the index after its subtree
+        int d = 0;                            // open cells
+        float ox = 0.f, oy = 0.f, oz = 0.f;   // calc_force(root)
+        int i = 0;
+        bool done = false;
+        while (!done) {
+            const float4 A = nodes[i].a;
+            const float4 B = nodes[i].b;
+            asm volatile("" :: "v"(A.w), "v"(B.y));
+            const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
+            const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
+            const int skip = __float_as_int(B.y);
+            ++n_vis;
+            float fx = 0.f, fy = 0.f, fz = 0.f;
+            bool value = true;               // this visit yields a value for the enclosing cell
+            if (B.x < theta2 * r2) {                                            // :192
+                const float r_dist = __builtin_sqrtf(r2 + eps2);                // :193
+                const float r_cubed = r_dist * r_dist * r_dist;                 // :194
+                const float k = ((g * A.w) / r_cubed);                          // :195
+                fx = rx * k; fy = ry * k; fz = rz * k;
+                ++n_acc;
+                i = skip;
+            } else if (skip == i + 1) {      // a leaf (or the empty root): no children, the fold of nothing is 0 (:197-202)
+                i = skip;
+            } else {                         // open the cell: its children fold into a fresh sum
+                if (d > 0) stack[size_t(d) * stack_stride + t] = make_float4(sx, sy, sz, __int_as_float(end));
+                ++d;
+                sx = sy = sz = 0.f;
+                end = skip;
+                i = i + 1;
+                value = false;
+            }
+            if (value) {
+                if (d == 0) { ox = fx; oy = fy; oz = fz; done = true; }        // the root itself was accepted (or is a leaf)
+                else { sx += fx; sy += fy; sz += fz; }                          // acc += child result
+            }
+            while (!done && d > 0 && i == end) {   // the innermost cell is finished: hand its sum up
+                const float vx = sx, vy = sy, vz = sz;
+                --d;
+                if (d == 0) { ox = vx; oy = vy; oz = vz; done = true; }
+                else {
+                    const float4 up = stack[size_t(d) * stack_stride + t];
+                    sx = up.x + vx; sy = up.y + vy; sz = up.z + vz;
+                    end = __float_as_int(up.w);
+                }
+            }
+        }
+        acc[b] = make_float4(ox, oy, oz, 0.f);  // :260
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_acc += __shfl_down(n_acc, off);
+        n_vis += __shfl_down(n_vis, off);
+    }
+    if ((threadIdx.x & 63) == 0 && counters) {
+        atomicAdd(&counters[0], (unsigned long long)n_acc);
+        atomicAdd(&counters[1], (unsigned long long)n_vis);
+    }
+}
+
 }  // namespace nbody
 extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group: 0 = automatic
 extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative, 2 = two lanes per body
@@ -308,6 +387,12 @@ __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ pl
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters, int leaf_direct) {
     if (t.n_order <= 0) return;
+    if (t.nested_stack && !fast_math && !leaf_direct && nbody_bh_walk_variant == 0) {
+        hipLaunchKernelGGL(k_bh_walk_nested, dim3((t.n_order + kWalkBlock - 1) / kWalkBlock), dim3(kWalkBlock), 0, s,
+                           reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g,
+                           g_soft2, theta2, counters, t.nested_stack, t.nested_stride);
+        return;
+    }
     WalkSplit sp;
     sp.n_seg = t.n_split; sp.first = t.split_first; sp.anc = t.split_anc; sp.n_anc = t.split_n_anc;
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;

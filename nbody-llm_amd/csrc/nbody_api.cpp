@@ -66,6 +66,8 @@ struct NbodyHandle {
     std::vector<int32_t> own_order;
     void* d_tree_ws = nullptr;   // device-build workspace (keys, sort buffers, scans)
     void* d_tree_cat = nullptr;  // sharded device build: concatenated positions, own-order list
+    float4* d_nested_stack = nullptr;  // strict Barnes-Hut: per-lane stack of open cells (k_bh_walk_nested)
+    size_t nested_cap = 0;
     size_t tree_ws_cap = 0;      // bodies it is sized for
     int* d_tree_info = nullptr;  // [3] node count, flags, bodies in the tree
     int* h_tree_info = nullptr;  // pinned
@@ -416,6 +418,22 @@ int ensure_tree_dev(NbodyHandle* h, size_t nodes, size_t order) {
 // positions, then one walk per body.
 int bh_walk_device_tree(NbodyHandle* h, bool* fell_back);
 
+// strict math with the reference leaf rule walks with the reference's nested sums (bit-exact): a stack
+// of NBODY_MAX_TREE_DEPTH + 1 open cells per own body, 16 bytes each
+int ensure_nested_stack(NbodyHandle* h, nbody::TreeDev* td) {
+    if (h->cfg.math_mode != NBODY_MATH_STRICT || h->cfg.leaf_mode != NBODY_LEAF_REFERENCE) return NBODY_OK;
+    const size_t lanes = (size_t(h->sh.seg_cap) + 255) / 256 * 256;
+    if (lanes > h->nested_cap) {
+        if (h->d_nested_stack) (void)hipFree(h->d_nested_stack);
+        h->d_nested_stack = nullptr; h->nested_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_nested_stack, lanes * size_t(NBODY_MAX_TREE_DEPTH + 1) * sizeof(float4)));
+        h->nested_cap = lanes;
+    }
+    td->nested_stack = h->d_nested_stack;
+    td->nested_stride = h->nested_cap;
+    return NBODY_OK;
+}
+
 int bh_forces(NbodyHandle* h) {
     Shard& sh = h->sh;
     {
@@ -480,6 +498,8 @@ int bh_forces(NbodyHandle* h) {
         constexpr int kMaxSplit = 32, kMaxAnc = 192;
         int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((8192 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
         K = std::max(1, std::min(kMaxSplit, K));
+        // strict math is the parity path: one segment, so every lane adds in the reference's order (bit-exact)
+        if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;
         while (K > 1 && size_t(K) * 16 > h->tree.n_nodes) K /= 2;
         if (K > 1) {
             if (!h->d_split) {
@@ -530,6 +550,10 @@ int bh_forces(NbodyHandle* h) {
             td.split_n_anc = h->d_split + kMaxSplit + 1;
             td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
         }
+    }
+    {
+        int rc_ns = ensure_nested_stack(h, &td);
+        if (rc_ns) return rc_ns;
     }
     {
         ForceTimer t(h);
@@ -613,6 +637,7 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     }
     int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((8192 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
     K = std::max(1, std::min(kMaxSplit, K));
+    if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
     while (K > 1 && K * 16 > n_nodes) K /= 2;
     if (n_order == 0) K = 1;
     nbody::TreeDev td;
@@ -635,6 +660,10 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
         }
         td.split_planes = h->d_walk_planes;
         td.split_stride = size_t(sh.seg_cap);
+    }
+    {
+        int rc_ns = ensure_nested_stack(h, &td);
+        if (rc_ns) return rc_ns;
     }
     {
         ForceTimer t(h);
@@ -761,7 +790,7 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_tree_ws, h->d_tree_cat, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
+                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info};
     for (void* p : host) if (p) (void)hipHostFree(p);

@@ -88,6 +88,56 @@ def test_steps_follow_the_oracle(gpu, orc):
     assert rel_err(got["velocity"], ref["velocity"]) < 1e-5
 
 
+@pytest.mark.parametrize("n,theta2,g_soft", [(2, 0.5, 0.0), (9, 1.0, 0.0), (300, 0.25, 0.0), (5000, 0.5, 0.02), (20000, 0.25, 0.01), (65536, 0.25, 0.01)])
+def test_strict_accelerations_are_bit_exact(gpu, orc, n, theta2, g_soft):
+    """Strict math walks with the reference's NESTED sums (k_bh_walk_nested: every opened cell folds its
+    children's results left to right from zero, barnes_hut.rs:196-202) on the bit-exact host tree: the
+    accelerations equal the oracle's bit for bit, not just to rounding."""
+    nb = gpu
+    sd, st = sd_st(nb, theta2=theta2, g_soft=g_soft, g=1.25)
+    ics = nb.plummer(n, seed=90 + n)
+    ref = ics.copy().astype(orc.P32)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=8)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+    assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    assert np.array_equal(got["acceleration"].view(np.uint32), ref["acceleration"].view(np.uint32))
+
+
+def test_strict_trajectory_is_bit_exact_with_escapes(gpu, orc):
+    """... and therefore whole trajectories: positions, velocities, accelerations after 12 steps in a
+    tight box (bodies leave on the way), single shard and three shards."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 3.0)
+    sd, st = sd_st(nb, theta2=0.25, g_soft=0.05, dt=1e-2)
+    ics = nb.plummer(4000, seed=97)
+    ref = ics.copy().astype(orc.P32)
+    for _ in range(12):
+        ref, _, _ = orc.bh_step_by(ref, sd, box[0], box[1], sd["dt"], threads=4)
+    assert len(ref) < 4000
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.STRICT) as sim:
+        sim.settings = st
+        sim.init()
+        sim.steps(12)
+        got = sim.get_points()
+    sims = [nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.STRICT, rank=r, world_size=3, capacity=len(ics)) for r in range(3)]
+    for s_ in sims:
+        s_.settings = st
+        s_.init()
+    for _ in range(12):
+        nb.sharded_step(sims)
+    got3 = np.concatenate([s_.get_points() for s_ in sims])
+    for s_ in sims:
+        s_.close()
+    for g_ in (got, got3):
+        assert len(g_) == len(ref)
+        for f in ("position", "velocity", "acceleration", "mass"):
+            assert np.array_equal(g_[f].view(np.uint32), ref[f].view(np.uint32)), f
+
+
 def test_fast_math_walk_same_nodes(gpu, orc):
     """fast math changes only the monopole evaluation (v_rsq_f32); the opening tests are the same."""
     nb = gpu

@@ -40,8 +40,8 @@ def test_brute_force_one_million_bodies_sampled_rows_and_momentum(gpu, orc):
 
 
 def test_barnes_hut_one_million_bodies_counts_and_accelerations(gpu, orc):
-    """1 048 576 bodies, theta = 0.5: node counts equal the threaded oracle's, accelerations to
-    rounding (the oracle's recursive build + walk takes a few seconds on 16 threads)."""
+    """1 048 576 bodies, theta = 0.5: node counts and accelerations equal the threaded
+    oracle's bit for bit (the oracle's recursive build + walk takes a few seconds on 16 threads)."""
     nb = gpu
     n = 1 << 20
     sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.25)
@@ -54,12 +54,12 @@ def test_barnes_hut_one_million_bodies_counts_and_accelerations(gpu, orc):
         got = sim.get_points()
         s = sim.stats()
     assert (s.interactions, s.node_visits) == (acc_n, vis_n)
-    assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+    assert np.array_equal(got["acceleration"].view(np.uint32), ref["acceleration"].view(np.uint32))   # strict: nested sums
 
 
 def test_barnes_hut_four_million_bodies_host_and_device_tree(gpu, orc):
     """configs[4]'s 4 194 304 bodies, theta = 0.5, on one GPU.  Host build + strict walk: accepted and
-    visited node counts equal the threaded oracle's exactly, accelerations to rounding.  Device build
+    visited node counts and the accelerations equal the threaded oracle's bit for bit.  Device build
     (kernels_tree.hip): same cells, centres of mass from f64 prefix sums instead of the reference's
     sequential f32 folds, so a few opening tests sit on the other side of their threshold -- counts
     within 1e-3; a flipped test moves one body's acceleration by that node's
@@ -78,7 +78,7 @@ def test_barnes_hut_four_million_bodies_host_and_device_tree(gpu, orc):
         host = sim.get_points()["acceleration"]
         s = sim.stats()
     assert (s.interactions, s.node_visits) == (acc_n, vis_n)
-    assert rel_err(host, ref["acceleration"]) < 1e-5
+    assert np.array_equal(host.view(np.uint32), ref["acceleration"].view(np.uint32))   # strict: nested sums, bit for bit
     del ref
     with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as sim:
         sim.settings = nb.Settings(**sd)
