@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ pl
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters, int leaf_direct) {
     if (t.n_order <= 0) return;
-    if (t.nested_stack && !fast_math && !leaf_direct && nbody_bh_walk_variant == 0) {
+    if (t.nested_stack && !fast_math && !leaf_direct) {  // strict math: always the parity kernel
         hipLaunchKernelGGL(k_bh_walk_nested, dim3((t.n_order + kWalkBlock - 1) / kWalkBlock), dim3(kWalkBlock), 0, s,
                            reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g,
                            g_soft2, theta2, counters, t.nested_stack, t.nested_stride);
@@ -397,11 +397,12 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     sp.n_seg = t.n_split; sp.first = t.split_first; sp.anc = t.split_anc; sp.n_anc = t.split_n_anc;
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
     dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
-    const int variant = leaf_direct ? 0 : nbody_bh_walk_variant;  // the alternative walks know the reference leaf rule only
+    // the alternative walks are fast-math experiments with the reference leaf rule only
+    const int variant = (leaf_direct || !fast_math) ? 0 : nbody_bh_walk_variant;
     if (variant == 2) grid.x = (2 * t.n_order + kWalkBlock - 1) / kWalkBlock;
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
-    if (variant == 1) { if (fast_math) WALK(k_bh_walk_wave, true); else WALK(k_bh_walk_wave, false); }
-    else if (variant == 2) { if (fast_math) WALK(k_bh_walk_pair, true); else WALK(k_bh_walk_pair, false); }
+    if (variant == 1) WALK(k_bh_walk_wave, true);
+    else if (variant == 2) WALK(k_bh_walk_pair, true);
     else if (leaf_direct) { if (fast_math) WALK(k_bh_walk, true, true); else WALK(k_bh_walk, false, true); }
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK

@@ -158,6 +158,7 @@ def test_fast_math_walk_same_nodes(gpu, orc):
 @pytest.mark.parametrize("math", ["strict", "fast"])
 @pytest.mark.parametrize("n,split", [(3001, 0), (777, 1), (20000, 4)])
 def test_alternative_walk_kernels_same_nodes(gpu, orc, variant, math, n, split):
+    # (strict math ignores the switch: it always walks with the parity kernel)
     """The selectable walk kernels -- 1: wave-cooperative (one scalar node load per wave), 2: two lanes
     per body (one contiguous 32-byte request per visit) -- evaluate exactly the opening tests of the
     default one: node counts equal the oracle's, accelerations to rounding.  Odd body counts leave a
