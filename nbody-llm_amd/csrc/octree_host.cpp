@@ -21,6 +21,11 @@
 //
 // Compiled with -ffp-contract=off (x*m must round before it is added).
 #include "octree_host.h"
+
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 #include "../../include/nbody_hip.h"
 
 #include <chrono>
@@ -38,9 +43,59 @@ namespace nbody {
 // that wakes late simply finds nothing to claim), so a run costs no wake-up latency when the
 // workers are still spinning from the previous one -- a Barnes-Hut step calls run() a few dozen
 // times within ~1 ms -- and a late sleeper never delays the caller.
+// CPUs of the NUMA node the calling thread is running on ("0-63,128-191" in
+// /sys/devices/system/node/nodeN/cpulist); empty if the layout cannot be read
+static std::vector<int> numa_node_cpus_of_caller() {
+    std::vector<int> cpus;
+#if defined(__linux__)
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return cpus;
+    for (int node = 0; node < 64; ++node) {
+        char path[96];
+        std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        FILE* f = std::fopen(path, "r");
+        if (!f) break;
+        char buf[1024] = {0};
+        const bool ok = std::fgets(buf, sizeof buf, f) != nullptr;
+        std::fclose(f);
+        if (!ok) continue;
+        std::vector<int> list;
+        bool mine = false;
+        for (char* p = buf; *p;) {
+            char* e = nullptr;
+            const long a = std::strtol(p, &e, 10);
+            if (e == p) break;
+            long b = a;
+            if (*e == '-') { p = e + 1; b = std::strtol(p, &e, 10); }
+            for (long c = a; c <= b; ++c) { list.push_back(int(c)); if (c == cpu) mine = true; }
+            p = (*e == ',') ? e + 1 : e;
+            if (*e != ',') break;
+        }
+        if (mine) return list;
+    }
+#endif
+    return cpus;
+}
+
 WorkerPool::WorkerPool(int threads) {
     int extra = std::max(0, threads - 1);
     for (int i = 0; i < extra; ++i) workers_.emplace_back([this] { loop(); });
+#if defined(__linux__)
+    // keep the workers on the caller's socket: the build is a few hundred microseconds of fork/join
+    // over arrays the caller touches too, and a worker across the inter-socket link doubles its
+    // memory latency (step-to-step build times of 0.8-1.2 ms on a 2-socket host).  A mask, not one
+    // core per thread: the scheduler keeps its freedom inside the node.  NBODY_POOL_NUMA=0 disables it.
+    const char* env = std::getenv("NBODY_POOL_NUMA");
+    if (extra > 0 && !(env && env[0] == '0')) {
+        const std::vector<int> cpus = numa_node_cpus_of_caller();
+        if (int(cpus.size()) >= threads) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int c : cpus) if (c < CPU_SETSIZE) CPU_SET(c, &set);
+            for (auto& w : workers_) (void)pthread_setaffinity_np(w.native_handle(), sizeof set, &set);
+        }
+    }
+#endif
 }
 
 WorkerPool::~WorkerPool() {
@@ -67,10 +122,38 @@ bool WorkerPool::try_one() {
     }
 }
 
+bool WorkerPool::try_background() {
+    int expect = 1;
+    if (bg_state_.load(std::memory_order_acquire) != 1 ||
+        !bg_state_.compare_exchange_strong(expect, 2, std::memory_order_acq_rel)) return false;
+    (*bg_fn_.load(std::memory_order_acquire))();
+    bg_state_.store(3, std::memory_order_release);
+    return true;
+}
+
+void WorkerPool::post_background(const std::function<void()>& fn) {
+    bg_fn_.store(&fn, std::memory_order_release);
+    bool wake;
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        bg_state_.store(1, std::memory_order_release);
+        wake = sleepers_ > 0;
+    }
+    if (wake) cv_.notify_one();
+}
+
+void WorkerPool::wait_background() {
+    if (bg_state_.load(std::memory_order_acquire) == 0) return;
+    try_background();  // nobody picked it up yet (no workers, or all busy): do it here
+    while (bg_state_.load(std::memory_order_acquire) != 3) __builtin_ia32_pause();
+    bg_state_.store(0, std::memory_order_release);
+}
+
 void WorkerPool::loop() {
     for (;;) {
         int idle = 0;
         while (!stop_.load(std::memory_order_relaxed)) {
+            if (try_background()) { idle = 0; continue; }
             if (try_one()) { idle = 0; continue; }
             if (++idle > 2000) break;  // ~50 us without work: go to sleep
             __builtin_ia32_pause();
@@ -78,7 +161,7 @@ void WorkerPool::loop() {
         if (stop_.load(std::memory_order_relaxed)) return;
         std::unique_lock<std::mutex> lk(m_);
         sleepers_++;
-        cv_.wait(lk, [&] { return stop_.load() || next_.load() < limit_.load(); });
+        cv_.wait(lk, [&] { return stop_.load() || next_.load() < limit_.load() || bg_state_.load() == 1; });
         sleepers_--;
         if (stop_.load()) return;
     }
@@ -310,7 +393,21 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         auto new_tnode = [&](const Box& bx) { TNode t; t.b = NodeB{bx.w * bx.w, 0, bx.w, -1}; for (int& c : t.child) c = -1; tn.push_back(t); return int(tn.size()) - 1; };
         const int big = std::max(2048, int(n / 64));
         const int chunk = std::max(1024, big / 2);
+        // the root's fold is a 4 x n-long dependent chain (~50 us at n = 65 536) nobody needs before the
+        // flatten below: it runs beside all the levels, over the caller's array (never written here;
+        // id order = the order fill() puts the bodies in)
+        NodeA root_fold{};
+        const std::function<void()> fold_root = [&] {
+            float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int sg = 0; sg < n_seg; ++sg) {
+                const float* p = pos4 + 4 * (size_t(sg) * seg_cap);
+                for (int j = 0; j < count[sg]; ++j, p += 4) { mass += p[3]; sx += p[0] * p[3]; sy += p[1] * p[3]; sz += p[2] * p[3]; }
+            }
+            root_fold = NodeA{sx / mass, sy / mass, sz / mass, mass};
+        };
+        pool.post_background(fold_root);
         pool.run(T, [&](int t) { const size_t c = (n + T - 1) / T; fill(std::min(n, size_t(t) * c), std::min(n, size_t(t + 1) * c)); });
+        lap("fill");
         std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root)}};
         struct Piece { int node; int k0, k1; };
         while (!level.empty()) {
@@ -320,14 +417,15 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
             std::vector<std::array<int, 8>> pcnt(pieces.size());
             const int NP = int(pieces.size()), NB = int(level.size());
             pool.run(NP + NB, [&](int t) {
-                if (t >= NP) {  // the node's fold
-                    const Big& g = level[t - NP];
+                if (t < NB) {  // the node's fold (handed out first: they are the long tasks of the run)
+                    const Big& g = level[t];
+                    if (g.depth == 0) return;  // the root's runs in the background
                     float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
                     for (int k = 0; k < g.n; ++k) { const Item& it = g.src[k]; mass += it.m; sx += it.x * it.m; sy += it.y * it.m; sz += it.z * it.m; }
                     tn[g.self].a = NodeA{sx / mass, sy / mass, sz / mass, mass};
                     return;
                 }
-                const Piece& pc = pieces[t];
+                const Piece& pc = pieces[t - NB];
                 const Big& g = level[pc.node];
                 std::array<int, 8> c{};
                 for (int k = pc.k0; k < pc.k1; ++k) {
@@ -336,7 +434,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
                     g.code[k] = uint8_t(o);
                     c[o]++;
                 }
-                pcnt[t] = c;
+                pcnt[t - NB] = c;
             });
             // per node: orthant starts, then per piece: its write offsets (stable: pieces in order)
             std::vector<std::array<int, 8>> nstart(NB), ntot(NB), poff(NP);
@@ -376,7 +474,10 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
                 }
             }
             level.swap(next);
+            if (timing) { char nm[32]; std::snprintf(nm, sizeof nm, "L nb=%d np=%d", NB, NP); lap(nm); }
         }
+        pool.wait_background();
+        tn[0].a = root_fold;
         // flatten the big-node tree in pre-order
         std::vector<int> stack{0};
         std::vector<int> open_end;  // entries whose `end` is patched when their subtree is complete

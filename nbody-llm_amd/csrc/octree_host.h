@@ -21,6 +21,10 @@ public:
     int size() const { return int(workers_.size()) + 1; }  // workers + the calling thread
     // runs fn(task) for task in [0, n_tasks), tasks handed out dynamically; returns when all done
     void run(int n_tasks, const std::function<void(int)>& fn);
+    // one background task beside the runs: taken by the first worker that looks for work (or by the
+    // caller in wait_background if none did); fn must stay alive until wait_background returns
+    void post_background(const std::function<void()>& fn);
+    void wait_background();
 
 private:
     void loop();
@@ -34,6 +38,9 @@ private:
     std::atomic<int> n_{0};             // size of the open run
     std::atomic<int> done_{0};          // tasks of the open run that have finished
     std::atomic<bool> stop_{false};
+    std::atomic<const std::function<void()>*> bg_fn_{nullptr};
+    std::atomic<int> bg_state_{0};      // 0 none, 1 posted, 2 running, 3 done
+    bool try_background();
     int sleepers_ = 0;                  // under m_
 };
 
