@@ -214,13 +214,22 @@ def main():
                                "frac": tf / FP32_VALU_PEAK_TF, "flop_per_interaction": FLOP_PER_INTERACTION,
                                "interactions_per_launch": k_inter / max(1.0, launches)}
         if args.workload == "bh" and avg_kernel_ms > 0:
-            # the walk's node records come out of L1/L2, not HBM (frac above can exceed 1): what bounds it
-            # is the L1 tag pipeline, one 16-byte gather per lane per look-up, two look-ups per visit
-            # (TCP_TOTAL_CACHE_ACCESSES in tools/pmc_bh.sh).  Cycles at the 2.4 GHz peak clock.
-            acc_per_cu_cycle = 2.0 * (visits / world) / max(1.0, launches) / (avg_kernel_ms * 1e-3 * 2.4e9) / 256.0
-            roofline["l1"] = {"bound": "l1-tag-rate", "achieved": acc_per_cu_cycle, "peak": 1.0,
-                              "unit": "cache accesses/cycle/CU", "frac": acc_per_cu_cycle, "accesses_per_visit": 2,
-                              "note": "node records are served by L1/L2: the hbm fraction above counts algorithmic bytes; ~1 access per cycle per CU is the measured ceiling of divergent 16-byte gathers (cycles counted at 2.4 GHz)"}
+            # the walk's node records come out of L1/L2, not HBM (frac above can exceed 1): what bounds it is
+            # the L1/TA pipeline serving divergent 16-byte gathers.  Cache-line
+            # accesses per visit from the PMC pass kept in profiles/ (TCP_TOTAL_CACHE_ACCESSES, tools/pmc_bh.sh).
+            per_visit = None
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_bh.json")))
+                per_visit = pj["TCP_TOTAL_CACHE_ACCESSES_per_launch"] / 1.2e8
+            except Exception:
+                per_visit = None
+            if per_visit:
+                acc_per_cu_cycle = per_visit * (visits / world) / max(1.0, launches) / (avg_kernel_ms * 1e-3 * 2.4e9) / 256.0
+                roofline["l1"] = {"bound": "l1-ta-pipeline", "achieved": acc_per_cu_cycle, "peak": 1.0,
+                                  "unit": "cache-line accesses/cycle/CU", "frac": acc_per_cu_cycle,
+                                  "accesses_per_visit": per_visit,
+                                  "note": "node records are served by L1/L2 (the hbm fraction above counts algorithmic bytes); "
+                                          "one cache-line access per cycle per CU nominal, cycles counted at 2.4 GHz"}
         result = {
             "metric": "pairwise_interactions_per_sec", "value": value, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

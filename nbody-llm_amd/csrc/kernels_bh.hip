@@ -60,8 +60,10 @@ __device__ __forceinline__ int walk_entry(const NodeDev* __restrict__ nodes, con
     return s0;  // every ancestor was opened: the walk arrives at first[seg] itself
 }
 
+__device__ unsigned long long nbody_bh_stamps[3 * 16384];  // diagnostic build only (DBG): per wave start, end (100 MHz ticks), iterations
+
 // DIRECT = NBODY_LEAF_DIRECT: the walk of src/llm/barnes_hut.rs:915-997 on the same tree (see nbody_hip.h)
-template <bool FAST, bool DIRECT = false>
+template <bool FAST, bool DIRECT = false, bool DBG = false>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restrict__ nodes, int n_nodes,
                                                         const int* __restrict__ order, int n_order,
                                                         const float4* __restrict__ own_pos, float4* __restrict__ acc,
@@ -71,6 +73,8 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
     const int seg = blockIdx.y;
     const int s1 = split.first[seg + 1];
     unsigned int n_acc = 0, n_vis = 0;
+    unsigned long long r_beg = 0;
+    if (DBG) r_beg = __builtin_amdgcn_s_memrealtime();
     if (t < n_order) {
         const int b = order[t];
         const float4 p = own_pos[b];
@@ -125,6 +129,14 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
             }
         }
         (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+    }
+    if (DBG) {
+        unsigned int it = n_vis;
+        for (int off = 32; off > 0; off >>= 1) it = max(it, (unsigned int)__shfl_down(it, off));
+        const int w = (blockIdx.y * gridDim.x + blockIdx.x) * (kWalkBlock / 64) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && w < 16384) {
+            nbody_bh_stamps[3 * w] = r_beg; nbody_bh_stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime(); nbody_bh_stamps[3 * w + 2] = it;
+        }
     }
     // one atomic pair per wave
     for (int off = 32; off > 0; off >>= 1) {
@@ -213,13 +225,12 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
 // Variant 2: TWO lanes per body.  A visit needs the node's 32-byte record; one lane fetches it as two
 // 16-byte loads (two L1 tag look-ups per visit, which is what bounds k_bh_walk: 0.87 cache accesses
 // per cycle per CU), a pair of neighbouring lanes fetches it as the two halves of ONE contiguous
-// 32-byte request (measured: 2.8x fewer L1 accesses).  The even lane holds {com, mass}, takes
+// 32-byte request (measured: 1.0e8 cache-line accesses per launch against 1.5e8).  The even lane holds {com, mass}, takes
 // width^2 and the skip link from its odd neighbour by DPP, walks, and hands the next node index back;
 // the odd lane executes the same instructions on meaningless values (its branch outcomes are never
 // used: every DPP sits outside the divergent region, where both lanes of a pair are active together).
 // Result at N = 65 536: 0.39 ms with the node range split 4 ways, the same as the per-lane walk's
-// 0.38 ms (8 ways): the L1 is relieved (0.35 accesses per cycle) but twice the wave-instructions are
-// issued per visit and the kernel becomes issue/latency bound instead.  Letting each lane pair walk
+// 0.38 ms (8 ways): the L1 is relieved but twice the wave-instructions are issued per visit.  Letting each lane pair walk
 // two bodies at once (two loads in flight per wave) was slower still (0.43 ms).  Kept selectable.
 __device__ __forceinline__ float pair_from_odd(float v) {   // quad_perm [1,1,3,3]: both lanes read the odd lane
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xF5, 0xF, 0xF, true));
@@ -366,6 +377,10 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_nested(const NodeDev* __
 }
 
 }  // namespace nbody
+extern "C" int nbody_bh_walk_debug = 0;    // 1: per-wave start/end stamps (tools/bh_wave_times.py)
+extern "C" int nbody_bh_read_stamps(unsigned long long* out, int n_waves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbody::nbody_bh_stamps), sizeof(unsigned long long) * 3 * n_waves) == hipSuccess ? 0 : -1;
+}
 extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group: 0 = automatic
 extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative, 2 = two lanes per body
 namespace nbody {
@@ -404,6 +419,7 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     if (variant == 1) WALK(k_bh_walk_wave, true);
     else if (variant == 2) WALK(k_bh_walk_pair, true);
     else if (leaf_direct) { if (fast_math) WALK(k_bh_walk, true, true); else WALK(k_bh_walk, false, true); }
+    else if (nbody_bh_walk_debug && fast_math) WALK(k_bh_walk, true, false, true);
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
     if (t.n_split > 1)

@@ -1,0 +1,39 @@
+"""Diagnostic: when do the waves of the Barnes-Hut walk start and end inside one launch, and how many
+iterations does each run?  (DBG instantiation of k_bh_walk: s_memrealtime stamps per wave.)"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft
+nb = graft.load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+splits = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8]
+dbg = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_debug")
+split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+ics = nb.plummer(n)
+sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE)
+sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.25)
+for K in splits:
+    split.value = K
+    dbg.value = 0
+    for _ in range(40):
+        sim.update_forces()
+    sim.sync()
+    dbg.value = 1
+    sim.update_forces(); sim.sync()
+    dbg.value = 0
+    Kw = K if K > 0 else max(1, min(32, 8192 // ((n + 63) // 64)))   # 0 = automatic
+    nw = min(16384, Kw * ((n + 255) // 256) * 4)
+    buf = (ctypes.c_ulonglong * (3 * nw))()
+    assert nb.lib.nbody_bh_read_stamps(buf, nw) == 0
+    st = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 3).astype(np.float64)
+    t0 = st[:, 0].min()
+    beg, end, it = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, st[:, 2]   # us
+    span = end.max()
+    life = end - beg
+    print(f"K={K}: {nw} waves, launch span {span:.1f} us; wave starts: median {np.median(beg):.1f} max {beg.max():.1f} us; "
+          f"ends: 25% {np.quantile(end,0.25):.1f} 50% {np.median(end):.1f} 75% {np.quantile(end,0.75):.1f} 95% {np.quantile(end,0.95):.1f} us")
+    print(f"      iterations per wave (max lane): median {np.median(it):.0f} 90% {np.quantile(it,0.9):.0f} 99% {np.quantile(it,0.99):.0f} max {it.max():.0f}; "
+          f"sum {it.sum():.3e}; cycles per iteration of the longest waves ~ {np.median((life*2400/np.maximum(it,1))[it > np.quantile(it,0.99)]):.0f}")
+    alive = [(end > f * span).mean() for f in (0.25, 0.5, 0.75, 0.9)]
+    print("      waves still running at 25/50/75/90 % of the span:", " ".join(f"{a*100:.0f}%" for a in alive))
+split.value = 0
