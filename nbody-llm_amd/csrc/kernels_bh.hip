@@ -135,7 +135,10 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
         for (int off = 32; off > 0; off >>= 1) it = max(it, (unsigned int)__shfl_down(it, off));
         const int w = (blockIdx.y * gridDim.x + blockIdx.x) * (kWalkBlock / 64) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0 && w < 16384) {
-            nbody_bh_stamps[3 * w] = r_beg; nbody_bh_stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime(); nbody_bh_stamps[3 * w + 2] = it;
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+            nbody_bh_stamps[3 * w] = r_beg; nbody_bh_stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+            nbody_bh_stamps[3 * w + 2] = (unsigned long long)it | ((unsigned long long)hw << 20) | ((unsigned long long)(xcc & 0xF) << 52);
         }
     }
     // one atomic pair per wave

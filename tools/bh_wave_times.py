@@ -25,7 +25,14 @@ for K in splits:
     nw = min(16384, Kw * ((n + 255) // 256) * 4)
     buf = (ctypes.c_ulonglong * (3 * nw))()
     assert nb.lib.nbody_bh_read_stamps(buf, nw) == 0
-    st = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 3).astype(np.float64)
+    raw = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 3)
+    st = raw.astype(np.float64)
+    st[:, 2] = (raw[:, 2] & np.uint64(0xFFFFF)).astype(np.float64)
+    hw = (raw[:, 2] >> np.uint64(20)) & np.uint64(0xFFFFFFFF)
+    xcc = ((raw[:, 2] >> np.uint64(52)) & np.uint64(0xF)).astype(np.int64)
+    # HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
+    cu = ((hw >> np.uint64(8)) & np.uint64(0xF)).astype(np.int64); sh = ((hw >> np.uint64(12)) & np.uint64(1)).astype(np.int64); se = ((hw >> np.uint64(13)) & np.uint64(7)).astype(np.int64)
+    place = ((xcc * 8 + se) * 2 + sh) * 16 + cu   # a CU
     t0 = st[:, 0].min()
     beg, end, it = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, st[:, 2]   # us
     span = end.max()
@@ -36,4 +43,19 @@ for K in splits:
           f"sum {it.sum():.3e}; cycles per iteration of the longest waves ~ {np.median((life*2400/np.maximum(it,1))[it > np.quantile(it,0.99)]):.0f}")
     alive = [(end > f * span).mean() for f in (0.25, 0.5, 0.75, 0.9)]
     print("      waves still running at 25/50/75/90 % of the span:", " ".join(f"{a*100:.0f}%" for a in alive))
+    # which (group block, segment) pairs share a CU?  wave w = (seg * n_blocks + block) * 4 + wave-in-block
+    n_blocks = (n + 255) // 256
+    wid = np.arange(nw)
+    seg_of, blk_of = (wid // 4) // n_blocks, (wid // 4) % n_blocks
+    cus = np.unique(place)
+    same_seg, spread = [], []
+    for c in cus[:64]:
+        m = place == c
+        segs, blks = seg_of[m], blk_of[m]
+        same_seg.append(len(np.unique(segs)))
+        spread.append(blks.max() - blks.min())
+    print(f"      {len(cus)} CUs seen; per CU: {np.mean([ (place==c).sum() for c in cus]):.1f} waves; distinct segments per CU median {np.median(same_seg):.0f}; "
+          f"group-block spread per CU median {np.median(spread):.0f} of {n_blocks}")
+    c0 = cus[0]; m = place == c0
+    print("      CU", c0, "holds (segment, block):", sorted(set(zip(seg_of[m].tolist(), blk_of[m].tolist())))[:16])
 split.value = 0
