@@ -20,7 +20,8 @@
 
 namespace nbody {
 
-constexpr int kWalkBlock = 256;
+constexpr int kWalkBlock = 64;   // one wave per workgroup: four body groups from different parts of the tree per CU (0.33 ms against 0.36 with 256)
+constexpr unsigned kCounterSlots = NBODY_WALK_COUNTER_SLOTS;  // {accepted, visited} pairs the waves' counts are spread over
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 struct alignas(32) NodeDev { float4 a; float4 b; };  // {com, mass}, {width^2, skip bits, width, leaf body}
@@ -147,8 +148,11 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
         n_vis += __shfl_down(n_vis, off);
     }
     if ((threadIdx.x & 63) == 0 && counters) {
-        atomicAdd(&counters[0], (unsigned long long)n_acc);
-        atomicAdd(&counters[1], (unsigned long long)n_vis);
+        // one atomic pair per wave, spread over kCounterSlots address pairs: 16 384 atomics on ONE address
+        // pair serialise in L2 at ~13 ns each (0.21 ms per walk at 8 segments, measured with theta2 = 1e9)
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
     }
 }
 
@@ -219,8 +223,11 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
         n_vis += __shfl_down(n_vis, off);
     }
     if ((threadIdx.x & 63) == 0 && counters) {
-        atomicAdd(&counters[0], (unsigned long long)n_acc);
-        atomicAdd(&counters[1], (unsigned long long)n_vis);
+        // one atomic pair per wave, spread over kCounterSlots address pairs: 16 384 atomics on ONE address
+        // pair serialise in L2 at ~13 ns each (0.21 ms per walk at 8 segments, measured with theta2 = 1e9)
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
     }
 }
 
@@ -295,8 +302,11 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_pair(const NodeDev* __re
         n_vis += __shfl_down(n_vis, off);
     }
     if ((threadIdx.x & 63) == 0 && counters) {
-        atomicAdd(&counters[0], (unsigned long long)n_acc);
-        atomicAdd(&counters[1], (unsigned long long)n_vis);
+        // one atomic pair per wave, spread over kCounterSlots address pairs: 16 384 atomics on ONE address
+        // pair serialise in L2 at ~13 ns each (0.21 ms per walk at 8 segments, measured with theta2 = 1e9)
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
     }
 }
 
@@ -374,8 +384,11 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_nested(const NodeDev* __
         n_vis += __shfl_down(n_vis, off);
     }
     if ((threadIdx.x & 63) == 0 && counters) {
-        atomicAdd(&counters[0], (unsigned long long)n_acc);
-        atomicAdd(&counters[1], (unsigned long long)n_vis);
+        // one atomic pair per wave, spread over kCounterSlots address pairs: 16 384 atomics on ONE address
+        // pair serialise in L2 at ~13 ns each (0.21 ms per walk at 8 segments, measured with theta2 = 1e9)
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
     }
 }
 

@@ -76,7 +76,7 @@ struct NbodyHandle {
     int* h_split = nullptr;      // pinned mirror
     float4* d_walk_planes = nullptr;
     size_t walk_planes_cap = 0;  // float4 entries
-    unsigned long long* d_counters = nullptr;  // [2] accepted, visited
+    unsigned long long* d_counters = nullptr;  // [NBODY_WALK_COUNTER_SLOTS][2] accepted, visited (summed on read)
     unsigned long long* h_counters = nullptr;  // pinned
 
     // symmetric all-pairs kernel (fast math, single shard, n >= kSymMinBodies)
@@ -858,9 +858,9 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
         h->tree.alloc = pinned_alloc;
         h->tree.release = pinned_free;
         CREATE_TRY(hipHostMalloc(&h->h_pos, size_t(sh.n_seg) * cap * sizeof(float4), hipHostMallocDefault));
-        CREATE_TRY(hipMalloc(&h->d_counters, 2 * sizeof(unsigned long long)));
-        CREATE_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
-        CREATE_TRY(hipHostMalloc(&h->h_counters, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        CREATE_TRY(hipMalloc(&h->d_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(h->d_counters, 0, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), h->stream));
+        CREATE_TRY(hipHostMalloc(&h->h_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), hipHostMallocDefault));
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
@@ -1125,11 +1125,13 @@ int nbody_stats(NbodyHandle* h, NbodyStats* out) {
     rc = drain_events(h);
     if (rc) return rc;
     if (h->d_counters) {
-        HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        h->stats.interactions = h->h_counters[0];
-        h->stats.force_kernel_interactions = h->h_counters[0];  // the walk kernel evaluates all of them
-        h->stats.node_visits = h->h_counters[1];
+        unsigned long long acc_sum = 0, vis_sum = 0;
+        for (unsigned k = 0; k < NBODY_WALK_COUNTER_SLOTS; ++k) { acc_sum += h->h_counters[2 * k]; vis_sum += h->h_counters[2 * k + 1]; }
+        h->stats.interactions = acc_sum;
+        h->stats.force_kernel_interactions = acc_sum;  // the walk kernel evaluates all of them
+        h->stats.node_visits = vis_sum;
     }
     *out = h->stats;
     return NBODY_OK;
@@ -1145,7 +1147,7 @@ int nbody_reset_stats(NbodyHandle* h) {
     h->stats = NbodyStats{};
     h->stats.tree_nodes = nodes;
     if (h->d_counters) {
-        HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return NBODY_OK;

@@ -22,7 +22,7 @@ for K in splits:
     sim.update_forces(); sim.sync()
     dbg.value = 0
     Kw = K if K > 0 else max(1, min(32, 8192 // ((n + 63) // 64)))   # 0 = automatic
-    nw = min(16384, Kw * ((n + 255) // 256) * 4)
+    nw = min(16384, Kw * ((n + 63) // 64))
     buf = (ctypes.c_ulonglong * (3 * nw))()
     assert nb.lib.nbody_bh_read_stamps(buf, nw) == 0
     raw = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 3)

@@ -10,7 +10,7 @@ split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
 for math in (nb.FAST,):
     sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BARNES_HUT, math_mode=math)
     sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.25)
-    for v, k in ((0, 1), (0, 4), (0, 8), (0, 12), (2, 4), (1, 8)):
+    for v, k in ((0, 4), (0, 8), (0, 12), (0, 16), (0, 24), (2, 4), (2, 8), (1, 8), (0, 8)):
         var.value = v; split.value = k
         sim.steps(3); sim.sync()
         sim.set_profiling(True); sim.reset_stats()
