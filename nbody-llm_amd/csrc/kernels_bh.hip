@@ -64,13 +64,13 @@ __device__ __forceinline__ int walk_entry(const NodeDev* __restrict__ nodes, con
 __device__ unsigned long long nbody_bh_stamps[3 * 16384];  // diagnostic build only (DBG): per wave start, end (100 MHz ticks), iterations
 
 // DIRECT = NBODY_LEAF_DIRECT: the walk of src/llm/barnes_hut.rs:915-997 on the same tree (see nbody_hip.h)
-template <bool FAST, bool DIRECT = false, bool DBG = false>
-__global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restrict__ nodes, int n_nodes,
+template <bool FAST, bool DIRECT = false, bool DBG = false, int BLOCK = kWalkBlock>
+__global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ nodes, int n_nodes,
                                                         const int* __restrict__ order, int n_order,
                                                         const float4* __restrict__ own_pos, float4* __restrict__ acc,
                                                         float g, float eps2, float theta2,
                                                         unsigned long long* __restrict__ counters, WalkSplit split) {
-    const int t = blockIdx.x * kWalkBlock + threadIdx.x;
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
     const int seg = blockIdx.y;
     const int s1 = split.first[seg + 1];
     unsigned int n_acc = 0, n_vis = 0;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk(const NodeDev* __restric
     if (DBG) {
         unsigned int it = n_vis;
         for (int off = 32; off > 0; off >>= 1) it = max(it, (unsigned int)__shfl_down(it, off));
-        const int w = (blockIdx.y * gridDim.x + blockIdx.x) * (kWalkBlock / 64) + (threadIdx.x >> 6);
+        const int w = (blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0 && w < 16384) {
             const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
             const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
@@ -434,6 +434,15 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
     if (variant == 1) WALK(k_bh_walk_wave, true);
     else if (variant == 2) WALK(k_bh_walk_pair, true);
+    else if (t.n_split <= 2 && !nbody_bh_walk_debug) {
+        // enough bodies to fill the chip with one or two segments (N >= ~2.5e5): 256-thread workgroups are up to
+        // 10 % faster there (6.2 against 6.8 ms at N = 2^20); with more segments one-wave workgroups win (kWalkBlock)
+        grid = dim3((t.n_order + 255) / 256, t.n_split);
+#define WALK256(...) hipLaunchKernelGGL((k_bh_walk<__VA_ARGS__, false, 256>), grid, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
+        if (leaf_direct) { if (fast_math) WALK256(true, true); else WALK256(false, true); }
+        else { if (fast_math) WALK256(true, false); else WALK256(false, false); }
+#undef WALK256
+    }
     else if (leaf_direct) { if (fast_math) WALK(k_bh_walk, true, true); else WALK(k_bh_walk, false, true); }
     else if (nbody_bh_walk_debug && fast_math) WALK(k_bh_walk, true, false, true);
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
