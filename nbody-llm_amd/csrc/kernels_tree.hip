@@ -92,16 +92,20 @@ __global__ __launch_bounds__(256) void k_tree_delta(const unsigned long long* __
     sums[k] = Sum4{double(p.w), double(p.w) * double(p.x), double(p.w) * double(p.y), double(p.w) * double(p.z)};
 }
 
+// One thread per NODE (not per body: the first body of a big cell opens every level above it, and 15
+// cells x a 17-step binary search in one thread was the kernel's whole duration, 30 us).  Node idx
+// belongs to the body k with base[k] <= idx < base[k+1] (binary search); its t-th node is the cell of
+// depth delta[k-1]+1+t that the body opens, or -- the last one -- the body's leaf.
 __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __restrict__ keys,
                                                    const int* __restrict__ ids, const float4* __restrict__ pos,
                                                    const int* __restrict__ count, const signed char* __restrict__ delta,
                                                    const int* __restrict__ base, const Sum4* __restrict__ incl,
                                                    float width, float4* __restrict__ nodes, int node_cap,
                                                    int* __restrict__ order, int* __restrict__ out_info) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
     if (n == 0) {  // the reference's empty root (barnes_hut.rs:145)
-        if (k == 0) {
+        if (idx == 0) {
             if (node_cap >= 1) {
                 nodes[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                 nodes[1] = make_float4(width * width, __int_as_float(1), width, __int_as_float(-1));
@@ -111,48 +115,49 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
         }
         return;
     }
-    if (k >= n) return;
-    if (k == 0) out_info[2] = n;  // the live body count rides along with the node count (one read-back)
+    const int total = base[n - 1] + 1;  // the last sorted body opens no cell: only its leaf follows base[n-1]
+    if (idx == 0) { out_info[0] = total; out_info[2] = n; }  // (the live body count rides along: one read-back)
+    if (total > node_cap) { if (idx == 0) atomicOr(out_info + 1, 2); return; }
+    if (idx >= total) return;
+    int lo = 0, hi = n - 1;             // the body whose nodes include idx: last k with base[k] <= idx
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (base[mid] <= idx) lo = mid; else hi = mid - 1;
+    }
+    const int k = lo;
     const int d_next = delta[k];
     const int d_prev = (k > 0) ? delta[k - 1] : -1;
     const int opened = max(0, d_next - d_prev);
-    const int first = base[k];
-    const int total = base[n - 1] + 1;  // the last sorted body opens no cell: only its leaf follows base[n-1]
-    if (k == 0) out_info[0] = total;
-    if (total > node_cap) { if (k == 0) atomicOr(out_info + 1, 2); return; }
-    const unsigned long long key = keys[k];
-    const Sum4 before = (k > 0) ? incl[k - 1] : Sum4{0.0, 0.0, 0.0, 0.0};
-    // cells this body opens, shallowest first
-    for (int t = 0; t < opened; ++t) {
-        const int d = d_prev + 1 + t;                   // depth of the cell: its bodies share d levels
+    const int t = idx - base[k];
+    if (t < opened) {                   // a cell this body opens, shallowest first
+        const int d = d_prev + 1 + t;   // depth of the cell: its bodies share d levels
+        const unsigned long long key = keys[k];
         const int shift = 3 * (kLevels - d);
         const unsigned long long hi_key = key | ((shift >= 64) ? ~0ull : ((1ull << shift) - 1ull));
-        int lo = k, hi = n - 1;                          // last sorted body with key <= hi_key
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (keys[mid] <= hi_key) lo = mid; else hi = mid - 1;
+        int a = k, b = n - 1;           // last sorted body with key <= hi_key
+        while (a < b) {
+            const int mid = (a + b + 1) >> 1;
+            if (keys[mid] <= hi_key) a = mid; else b = mid - 1;
         }
-        const int j = lo;
+        const int j = a;
+        const Sum4 before = (k > 0) ? incl[k - 1] : Sum4{0.0, 0.0, 0.0, 0.0};
         const Sum4 upto = incl[j];
         const double m = upto.m - before.m;
         float w = width;
         for (int q = 0; q < d; ++q) w = w * 0.5f;       // create_orthant halves the width exactly
         const int skip = (j + 1 < n) ? base[j + 1] : total;
-        const int idx = first + t;
         nodes[2 * idx] = make_float4(float((upto.x - before.x) / m), float((upto.y - before.y) / m),
                                      float((upto.z - before.z) / m), float(m));
         nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(skip), w, __int_as_float(-1));
+    } else {                            // the body's leaf
+        const int ld = max(d_prev, d_next) + 1;
+        float w = width;
+        for (int q = 0; q < ld; ++q) w = w * 0.5f;
+        const int id = ids[k];
+        nodes[2 * idx] = pos[id];
+        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(idx + 1), w, __int_as_float(id));
+        order[k] = id;
     }
-    // the leaf
-    const int ld = max(d_prev, d_next) + 1;
-    float w = width;
-    for (int q = 0; q < ld; ++q) w = w * 0.5f;
-    const int id = ids[k];
-    const float4 p = pos[id];
-    const int idx = first + opened;
-    nodes[2 * idx] = p;
-    nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(idx + 1), w, __int_as_float(id));
-    order[k] = id;
 }
 
 // ancestors of the node-range split points (the walk's WalkSplit lists), root first.  Node t lies in
@@ -369,8 +374,10 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
         if (rocprim::exclusive_scan(tmp, tb, emit_count, base, 0, size_t(n), rocprim::plus<int>(), s) != hipSuccess) return -1;
         sum4_inclusive_scan(s, tmp, sums, incl, d_count, n);
     }
-    hipLaunchKernelGGL(k_tree_emit, grid, block, 0, s, keys, ids, pos, d_count, delta, base, incl, width, nodes, node_cap,
-                       order, out_info);
+    // one thread per node; their number is known on the device only, so one per node the array can hold
+    // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
+    hipLaunchKernelGGL(k_tree_emit, dim3((std::max(1, node_cap) + 255) / 256), block, 0, s, keys, ids, pos, d_count, delta, base,
+                       incl, width, nodes, node_cap, order, out_info);
     return 0;
 }
 
