@@ -752,6 +752,10 @@ int step_finish(NbodyHandle* h, float dt) {
     if (h->kick_pending) nbody::launch_kick_drift(h->stream, h->sh, int(h->n_local), dt);  // integrate_after_force
     h->kick_pending = false;
     HIP_TRY(h, hipGetLastError());
+    if (h->ev_pending.size() >= 4096) {  // profiling left on over a long run: fold the timings in now and then
+        rc = drain_events(h);
+        if (rc) return rc;
+    }
     h->elapsed += dt;                                                          // elapsed += dt
     h->stats.steps += 1;
     return NBODY_OK;
