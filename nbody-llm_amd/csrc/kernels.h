@@ -135,7 +135,9 @@ void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_
 // the walk's {accepted, visited} counters: this many u64 pairs, to be summed by the reader
 #define NBODY_WALK_COUNTER_SLOTS 1024u
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
-                    int fast_math, unsigned long long* counters /* [NBODY_WALK_COUNTER_SLOTS][2]: accepted, visited */, int leaf_direct = 0);
+                    int fast_math, unsigned long long* counters /* [NBODY_WALK_COUNTER_SLOTS][2]: accepted, visited */, int leaf_direct = 0,
+                    const float* kick_dt = nullptr /* fuse integrate_after_force into the plane reduction */,
+                    int* kicked = nullptr /* out: 1 if it was applied */);
 
 // diagnostics: f64 energies of the own segment against all segments; out = {KE, PE_pairs_sum}
 void launch_energy(hipStream_t s, const Shard& sh, int n_upper, double g_soft2, double* out2);

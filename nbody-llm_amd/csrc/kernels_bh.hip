@@ -401,9 +401,12 @@ extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group
 extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative, 2 = two lanes per body
 namespace nbody {
 
+// KICK: integrate_after_force (shared.rs:141-148) rides along, as in k_bf_sym_reduce
+template <bool KICK>
 __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ planes, int n_seg, size_t plane_stride,
                                                    const int* __restrict__ order, int n_order,
-                                                   float4* __restrict__ acc) {
+                                                   float4* __restrict__ acc, float4* __restrict__ pos,
+                                                   float4* __restrict__ vel, float dt) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_order) return;
     const int b = order[t];
@@ -413,10 +416,22 @@ __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ pl
         sx += v.x; sy += v.y; sz += v.z;
     }
     acc[b] = make_float4(sx, sy, sz, 0.f);
+    if (KICK) {
+        float4 p = pos[b], v = vel[b];
+        v.x += sx * dt;                 // shared.rs:144
+        v.y += sy * dt;
+        v.z += sz * dt;
+        p.x += (v.x * 0.5f) * dt;       // shared.rs:146
+        p.y += (v.y * 0.5f) * dt;
+        p.z += (v.z * 0.5f) * dt;
+        vel[b] = v;
+        pos[b] = p;
+    }
 }
 
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
-                    int fast_math, unsigned long long* counters, int leaf_direct) {
+                    int fast_math, unsigned long long* counters, int leaf_direct, const float* kick_dt, int* kicked) {
+    if (kicked) *kicked = 0;
     if (t.n_order <= 0) return;
     if (t.nested_stack && !fast_math && !leaf_direct) {  // strict math: always the parity kernel
         hipLaunchKernelGGL(k_bh_walk_nested, dim3((t.n_order + kWalkBlock - 1) / kWalkBlock), dim3(kWalkBlock), 0, s,
@@ -447,9 +462,17 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     else if (nbody_bh_walk_debug && fast_math) WALK(k_bh_walk, true, false, true);
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
-    if (t.n_split > 1)
-        hipLaunchKernelGGL(k_bh_reduce, dim3((t.n_order + 255) / 256), dim3(256), 0, s, t.split_planes, t.n_split,
-                           t.split_stride, t.order, t.n_order, sh.acc);
+    if (t.n_split > 1) {
+        const dim3 rg((t.n_order + 255) / 256);
+        if (kick_dt) {
+            hipLaunchKernelGGL(k_bh_reduce<true>, rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order,
+                               t.n_order, sh.acc, sh.own_pos(), sh.vel, *kick_dt);
+            if (kicked) *kicked = 1;
+        } else {
+            hipLaunchKernelGGL(k_bh_reduce<false>, rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order,
+                               t.n_order, sh.acc, sh.own_pos(), sh.vel, 0.f);
+        }
+    }
 }
 
 }  // namespace nbody

@@ -557,8 +557,11 @@ int bh_forces(NbodyHandle* h) {
     }
     {
         ForceTimer t(h);
+        int kicked = 0;
         nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
-                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT);
+                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT,
+                              h->kick_pending ? &h->kick_dt : nullptr, &kicked);
+        if (kicked) h->kick_pending = false;  // the plane reduction applied the kick + half drift
     }
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
@@ -667,8 +670,11 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     }
     {
         ForceTimer t(h);
+        int kicked = 0;
         nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
-                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT);
+                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT,
+                              h->kick_pending ? &h->kick_dt : nullptr, &kicked);
+        if (kicked) h->kick_pending = false;  // the plane reduction applied the kick + half drift
     }
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
