@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X: pairwise interactions/s (+ steps/s) of the
-N-body force-and-integrate step at N = 65 536, with the HBM/ALU roofline of the dominant kernel
-and the CPU oracle timed beside it.
+N-body force-and-integrate step at N = 65 536, with the roofline of the dominant kernel and the CPU
+oracle timed beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bf|bh] [--n BODIES]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one Simulation::step (half drift, retain, forces, kick + half drift) of ALL bodies.
-Inputs are resident in HBM before the timed region.  With N ranks the bodies are split into N
-contiguous index blocks; every rank exchanges its half-drifted positions once per step with an
-RCCL all-gather issued by the library itself (torch.distributed/gloo is control plane only:
-rendezvous, the ncclUniqueId broadcast, barriers and the max-over-ranks of the wall time).
-BASELINE's metric is quoted at N = 65 536 on 1/2/4/8 GPUs, i.e. total work fixed: "strong".
+Inputs are resident in HBM before the timed region.  The default line is configs[1] (65 536-body
+brute force, the configuration the metric is quoted on); on one GPU it also carries a `bh` object with
+configs[2] (65 536-body Barnes-Hut, theta = 0.5) run both ways -- octree built on the host every step
+(north_star's configuration) and built on the device -- each with its own step time, build / copy /
+walk split, node visits and roofline.  With N ranks the bodies are split into N contiguous index
+blocks; every rank exchanges its half-drifted positions once per step with an RCCL all-gather issued by
+the library itself (torch.distributed/gloo is control plane only: rendezvous, the ncclUniqueId
+broadcast, barriers and the max-over-ranks of the wall time).  BASELINE's metric is quoted at
+N = 65 536 on 1/2/4/8 GPUs, i.e. total work fixed: "strong".
+
+What bounds the kernels: the all-pairs kernel is fp32-VALU bound (O(N) data for
+O(N^2) arithmetic), so `roofline.bound` is "fp32-valu" and the HBM fraction BASELINE asks for rides
+along as `roofline.hbm`; the tree walk is bound by the L1/TA pipeline serving divergent 16-byte
+gathers (its node records come out of L1/L2: HBM traffic is ~2 % of peak), so its `roofline.bound` is
+"l1-ta" against the ceiling measured by tools/microbench_gather.hip (profiles/r02_gather_ceiling.json).
 """
 from __future__ import annotations
 
@@ -29,10 +39,24 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP32_VALU_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 vector = f32 MFMA rate
-FLOP_PER_INTERACTION = 20
+FP32_VALU_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 vector = 256 CUs x 256 flop/cycle x 2.4 GHz
+FLOP_PER_INTERACTION = 20    # the convention rates are quoted in
+FLOP_EXECUTED_SYM = 13       # what k_bf_sym issues: 17 VALU ops = 26 flop per UNORDERED pair = 2 interactions
 BF_BYTES_PER_BODY = 32       # K2 alone: 16 B {x,y,z,m} read + 16 B acceleration written, per launch
-BH_BYTES_PER_VISIT = 32      # K5: one 32-byte node record per opening test
+BH_BYTES_PER_BODY = 32       # K5: 16 B position read + 16 B acceleration written (node records: see l1-ta)
+CLOCK_HZ = 2.4e9             # nominal shader clock the per-cycle figures are quoted at
+N_CU = 256
+
+# which parity tests cover the kernel a given line times (say so in the line)
+PARITY = {
+    ("bf", "fast"): "fast math, tolerance not bit-exactness: tests/test_bf_gpu.py (acc <= 1e-5 of max|acc| vs the f32 oracle at "
+                    "N = 65 536; <= 3e-5 vs the bit-exact strict kernel; pos <= 1e-4 after 100 steps; |dE/E| < 1e-5 over 50 steps, "
+                    "an absolute bound -- the CPU oracle needs ~9 s per step at this N, no CPU trajectory is run)",
+    ("bf", "strict"): "strict math: bit-exact vs the oracle (tests/test_bf_gpu.py, tests/test_golden.py)",
+    ("bh", "fast"): "fast math: node counts exact, acc <= 1e-5 of max|acc| vs the oracle (tests/test_bh_gpu.py); device tree: "
+                    "structure bit-equal, counts within 1e-3 (tests/test_bh_device_tree_gpu.py)",
+    ("bh", "strict"): "strict math: accelerations and trajectories bit-exact vs the oracle (tests/test_bh_gpu.py, tests/test_large_gpu.py)",
+}
 
 
 def parse():
@@ -41,21 +65,32 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["bf", "bh"], default="bf",
-                    help="bf = configs[1] (65 536-body brute force, the metric's config); bh = configs[2]")
+                    help="bf = configs[1] (65 536-body brute force, the metric's config, + the bh object on one GPU); "
+                         "bh = configs[2] alone as the top-level line")
     ap.add_argument("--n", type=int, default=65536, help="bodies over all GPUs")
     ap.add_argument("--math", choices=["fast", "strict"], default="fast")
     ap.add_argument("--theta", type=float, default=0.5, help="Barnes-Hut opening angle (theta2 = theta^2)")
     ap.add_argument("--tree", choices=["host", "device"], default="host",
-                    help="Barnes-Hut octree build: host (north_star, bit-exact) or device (SURVEY F3)")
+                    help="--workload bh: octree build on the host (north_star, bit-exact) or on the device (SURVEY F3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bh", action="store_true", help="default line without the configs[2] object")
     ap.add_argument("--seed", type=int, default=20250523)
     return ap.parse_args()
+
+
+def load_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def cpu_baseline(orc, ics, settings, box, workload):
     """The oracle (a port of the reference's CPU path) on this box's host cores, bounded to ~10-30 s."""
     center, width = box
     n = len(ics)
+    flags = "g++ -O3 -ffp-contract=off, no -march=native (built off-box; oracle/Makefile)"
     if workload == "bf":
         # the reference loop is serial (brute_force.rs:70-81): one thread, one pass over all bodies
         # (~9 s at N = 65 536); larger N are cut to 65 536 bodies
@@ -71,7 +106,7 @@ def cpu_baseline(orc, ics, settings, box, workload):
         dt_mt = time.perf_counter() - t0
         mb = len(b)
         return {
-            "value": m * (m - 1) / dt, "unit": "interactions/s", "cores": 1, "kind": "port",
+            "value": m * (m - 1) / dt, "unit": "interactions/s", "cores": 1, "kind": "port", "build": flags,
             "sample": f"one update_forces pass over the first {m} bodies of the same Plummer set "
                       f"(serial symmetric pair loop as brute_force.rs:70-81, credited N(N-1) directed pairs), {dt:.1f} s",
             "threaded_context": {"value": mb * (mb - 1) / dt_mt, "cores": threads,
@@ -85,11 +120,132 @@ def cpu_baseline(orc, ics, settings, box, workload):
         acc, _ = orc.bh_update_forces(a, settings, center, width, threads=threads)
     dt = (time.perf_counter() - t0) / reps
     return {
-        "value": acc / dt, "unit": "interactions/s", "cores": threads, "kind": "port",
+        "value": acc / dt, "unit": "interactions/s", "cores": threads, "kind": "port", "build": flags,
         "steps_per_sec": 1.0 / dt,
         "sample": f"{reps} update_forces passes (recursive build + threaded recursive walk as "
                   f"barnes_hut.rs:143-203,250-263) over all {len(a)} bodies, {dt:.2f} s each",
     }
+
+
+def bf_roofline(args, world, n, kernel_ms, launches, k_inter):
+    """Dominant all-pairs kernel: fp32-VALU bound; the HBM fraction BASELINE asks for as a sub-field."""
+    avg_ms = kernel_ms / max(1.0, launches)
+    cross = os.environ.get("NBODY_CROSS_SYM", "1") != "0"
+    kernel = ("k_bf_strict" if args.math == "strict" else
+              "k_bf_sym" if (world == 1 and n >= 8192) else
+              ("k_bf_cross" if cross else "k_bf_os") if (world > 1 and -(-n // world) >= 2048) else "k_bf_fast")
+    inter_per_launch = k_inter / max(1.0, launches)
+    tf = FLOP_PER_INTERACTION * inter_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    alg_bytes = BF_BYTES_PER_BODY * n / world
+    gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    if world == 1 and n == 65536 and args.math == "fast":
+        pj = load_json("pmc_traffic_bf.json")
+        traffic = pj.get("hbm_bytes_per_launch") if pj else None
+    r = {
+        "bound": "fp32-valu", "kernel": kernel, "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+        "frac": tf / FP32_VALU_PEAK_TF, "traffic": traffic,
+        "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": inter_per_launch,
+        "avg_kernel_ms": avg_ms, "launches_timed": int(launches),
+        # O(N) bytes for O(N^2) flops: the HBM fraction is tiny by construction (SURVEY section 8d)
+        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None},
+    }
+    if kernel in ("k_bf_sym", "k_bf_cross"):
+        # the symmetric kernels evaluate every unordered pair once: 17 VALU ops = 26 flop per pair = 13 per
+        # directed interaction actually issued; the 20-flop figure credits the one-sided formulation's work
+        r["executed"] = {"flop_per_interaction": FLOP_EXECUTED_SYM, "achieved": tf * FLOP_EXECUTED_SYM / FLOP_PER_INTERACTION,
+                         "frac": tf * FLOP_EXECUTED_SYM / FLOP_PER_INTERACTION / FP32_VALU_PEAK_TF, "unit": "TFLOP/s"}
+    return r
+
+
+def bh_roofline(n_local, kernel_ms, launches, visits_per_launch, tree):
+    """The walk: L1/TA bound.  achieved = L1 cache-line accesses per cycle per CU = this run's
+    opening tests (one 32-byte node record each, two 16-byte gathers) per cycle per CU, from its visit count and
+    HIP-event kernel time, x the L1 line accesses per visit of the PMC pass kept in profiles/ (TCP_TOTAL_CACHE_ACCESSES
+    and the visit count of that same pass); peak = the line rate the same access pattern sustains in isolation with
+    fully divergent lanes (tools/microbench_gather.hip).  The visit rate against the microbenchmark's rows for 1 and
+    2 lanes per record, and the HBM figure from the PMC bytes, ride along."""
+    avg_ms = kernel_ms / max(1.0, launches)
+    ceil = load_json("r02_gather_ceiling.json") or {}
+    peak_lines = ceil.get("divergent_l1_line_accesses_per_cycle_per_cu")
+    vpc = visits_per_launch / (avg_ms * 1e-3 * CLOCK_HZ * N_CU) if avg_ms > 0 else 0.0
+    pj = load_json(f"pmc_traffic_bh_{tree}.json") or load_json("pmc_traffic_bh.json") or {}
+    traffic = pj.get("hbm_bytes_per_launch")
+    per_visit = None
+    if pj.get("TCP_TOTAL_CACHE_ACCESSES_per_launch"):
+        per_visit = pj["TCP_TOTAL_CACHE_ACCESSES_per_launch"] / pj.get("node_visits_per_launch", 1.2e8)  # both from the same PMC run
+    lines = per_visit * vpc if per_visit else None
+    rows = ceil.get("by_lanes_per_record_visits_per_cycle_per_cu") or {}
+    return {
+        "bound": "l1-ta", "kernel": "k_bh_walk (+ k_bh_reduce)", "achieved": lines, "peak": peak_lines,
+        "unit": "L1 cache-line accesses/cycle/CU", "frac": (lines / peak_lines) if (lines and peak_lines) else None,
+        "traffic": traffic,
+        "avg_kernel_ms": avg_ms, "launches_timed": int(launches), "visits_per_launch": visits_per_launch,
+        "clock_hz_assumed": CLOCK_HZ, "l1_line_accesses_per_visit": per_visit,
+        "visits_per_cycle_per_cu": vpc,
+        "visits_ceiling_divergent": rows.get("1"), "visits_ceiling_2_lanes_per_record": rows.get("2"),
+        "peak_source": ceil.get("source"),
+        "hbm": {"traffic_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
+                "algorithmic_bytes_per_launch": BH_BYTES_PER_BODY * n_local, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "note": "node records are served by L1/L2; algorithmic HBM bytes are positions in + accelerations out"},
+    }
+
+
+def run(nb, args, workload, tree, ics, box, st, rank, world, local_rank, dist, ident_fn):
+    """W warm-up + K timed steps of one workload; returns (elapsed, stats, n_after)."""
+    n = len(ics)
+    method = nb.BRUTE_FORCE if workload == "bf" else nb.BARNES_HUT
+    math_mode = nb.FAST if args.math == "fast" else nb.STRICT
+    sim = nb.Simulation(ics, *box, method=method, math_mode=math_mode, capacity=n, device=local_rank,
+                        rank=rank, world_size=world,
+                        tree_build=nb.TREE_DEVICE if tree == "device" else nb.TREE_HOST)
+    sim.settings = nb.Settings(**st)
+    if dist is not None and (world > 1 or os.environ.get("NBODY_BENCH_FORCE_COMM")):
+        sim.comm_init(ident_fn())
+    sim.init()
+
+    def barrier():
+        sim.sync()
+        if dist is not None:
+            dist.barrier()
+            sim.sync()
+
+    sim.steps(args.warmup)
+    sim.set_profiling(True)
+    sim.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    sim.steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = sim.stats()
+    sim.set_profiling(False)
+    n_after = sim.count_global() if world == 1 else None
+    sim.close()
+    return elapsed, stats, n_after
+
+
+def bh_record(args, n, tree, elapsed, stats):
+    visits = float(stats.node_visits)
+    launches = float(stats.force_launches)
+    rec = {
+        "workload": f"configs[2]: {n}-body Barnes-Hut theta={args.theta}" if n == 65536 else f"bh n={n}",
+        "tree_build": tree, "math": args.math,
+        "ms_per_step": 1e3 * elapsed / args.steps, "steps_per_sec": args.steps / elapsed,
+        "interactions_per_sec": float(stats.interactions) / elapsed,
+        "tree_nodes": int(stats.tree_nodes),
+        "node_visits_per_step": visits / args.steps, "accepted_per_step": float(stats.interactions) / args.steps,
+        "split_ms_per_step": {
+            "tree_build": stats.tree_build_ms / args.steps,     # host wall time in the build (device build: enqueue + read-back wait)
+            "tree_copy": stats.tree_copy_ms / args.steps,       # host build only: D2H positions + H2D nodes (incl. waiting for the previous step)
+            "walk_kernel": stats.force_kernel_ms / max(1.0, launches),
+        },
+        "roofline": bh_roofline(n, stats.force_kernel_ms, launches, visits / max(1.0, launches), tree),
+        "parity": PARITY[("bh", args.math)],
+    }
+    return rec
 
 
 def main():
@@ -126,36 +282,13 @@ def main():
     theta2 = args.theta * args.theta
     st = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=theta2)
     ics = nb.plummer(n, seed=args.seed)
-    method = nb.BRUTE_FORCE if args.workload == "bf" else nb.BARNES_HUT
-    math_mode = nb.FAST if args.math == "fast" else nb.STRICT
 
-    sim = nb.Simulation(ics, *box, method=method, math_mode=math_mode, capacity=n, device=local_rank,
-                        rank=rank, world_size=world,
-                        tree_build=nb.TREE_DEVICE if args.tree == "device" else nb.TREE_HOST)
-    sim.settings = nb.Settings(**st)
-    if dist is not None and (world > 1 or os.environ.get("NBODY_BENCH_FORCE_COMM")):
+    def ident_fn():
         ident = [nb.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
-        sim.comm_init(ident[0])
-    sim.init()
+        return ident[0]
 
-    def barrier():
-        sim.sync()
-        if dist is not None:
-            dist.barrier()
-            sim.sync()
-
-    sim.steps(args.warmup)
-    sim.set_profiling(True)
-    sim.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    sim.steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stats = sim.stats()
-    sim.set_profiling(False)
-    n_after = sim.count_global() if world == 1 else None
+    elapsed, stats, n_after = run(nb, args, args.workload, args.tree, ics, box, st, rank, world, local_rank, dist, ident_fn)
 
     if dist is not None:
         import torch
@@ -177,59 +310,10 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = interactions / elapsed
-        avg_kernel_ms = kernel_ms / max(1.0, launches)
-        bodies_per_launch = n / world
         if args.workload == "bf":
-            alg_bytes = BF_BYTES_PER_BODY * bodies_per_launch
-            cross = os.environ.get("NBODY_CROSS_SYM", "1") != "0"
-            kernel = ("k_bf_strict" if args.math == "strict" else
-                      "k_bf_sym" if (world == 1 and n >= 8192) else
-                      ("k_bf_cross" if cross else "k_bf_os") if (world > 1 and n // world >= 2048) else "k_bf_fast")
-            # interactions the timed (dominant) launches evaluated; k_bf_sym leaves ~2 % (own and
-            # opposite resident set) to the small companion kernel k_bf_sym_rest
-            flops_per_launch = FLOP_PER_INTERACTION * k_inter / max(1.0, launches)
+            roofline = bf_roofline(args, world, n, kernel_ms, launches, k_inter)
         else:
-            alg_bytes = BH_BYTES_PER_VISIT * (visits / world) / max(1.0, launches) + 32 * bodies_per_launch
-            kernel = "k_bh_walk"
-            flops_per_launch = None
-        achieved_gbs = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
-        if os.path.exists(tpath) and world == 1 and n == 65536:
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {
-            "bound": "hbm", "kernel": kernel, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "avg_kernel_ms": avg_kernel_ms, "launches_timed": int(launches),
-            "algorithmic_bytes_per_launch": alg_bytes,
-        }
-        if flops_per_launch is not None and avg_kernel_ms > 0:
-            tf = flops_per_launch / (avg_kernel_ms * 1e-3) / 1e12
-            # the all-pairs kernel is fp32-VALU bound, not HBM bound: this is
-            # the fraction that says how good the kernel is
-            roofline["alu"] = {"bound": "fp32-valu", "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": tf / FP32_VALU_PEAK_TF, "flop_per_interaction": FLOP_PER_INTERACTION,
-                               "interactions_per_launch": k_inter / max(1.0, launches)}
-        if args.workload == "bh" and avg_kernel_ms > 0:
-            # the walk's node records come out of L1/L2, not HBM (frac above can exceed 1): what bounds it is
-            # the L1/TA pipeline serving divergent 16-byte gathers.  Cache-line
-            # accesses per visit from the PMC pass kept in profiles/ (TCP_TOTAL_CACHE_ACCESSES, tools/pmc_bh.sh).
-            per_visit = None
-            try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_bh.json")))
-                per_visit = pj["TCP_TOTAL_CACHE_ACCESSES_per_launch"] / 1.2e8
-            except Exception:
-                per_visit = None
-            if per_visit:
-                acc_per_cu_cycle = per_visit * (visits / world) / max(1.0, launches) / (avg_kernel_ms * 1e-3 * 2.4e9) / 256.0
-                roofline["l1"] = {"bound": "l1-ta-pipeline", "achieved": acc_per_cu_cycle, "peak": 1.0,
-                                  "unit": "cache-line accesses/cycle/CU", "frac": acc_per_cu_cycle,
-                                  "accesses_per_visit": per_visit,
-                                  "note": "node records are served by L1/L2 (the hbm fraction above counts algorithmic bytes); "
-                                          "one cache-line access per cycle per CU nominal, cycles counted at 2.4 GHz"}
+            roofline = bh_roofline(n / world, kernel_ms, launches, (visits / world) / max(1.0, launches), args.tree)
         result = {
             "metric": "pairwise_interactions_per_sec", "value": value, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -248,17 +332,26 @@ def main():
                 "bodies_left_in_box": n_after,
             },
             "roofline": roofline,
+            "parity": PARITY[(args.workload, args.math)],
         }
         if args.workload == "bh":
-            result["bh"] = {"tree_build": args.tree, "tree_nodes": int(stats.tree_nodes), "node_visits_per_step": visits / args.steps,
-                            "tree_build_ms_per_step": stats.tree_build_ms / args.steps,
-                            "tree_copy_ms_per_step": stats.tree_copy_ms / args.steps}
-    sim.close()
+            result["bh"] = bh_record(args, n, args.tree, elapsed, stats)
+
+    # configs[2] beside the metric's line: both tree builds, one GPU only (the driver's N = 1 record)
+    if args.workload == "bf" and world == 1 and not args.no_bh:
+        bh = {}
+        for tree in ("host", "device"):
+            e2, s2, _ = run(nb, args, "bh", tree, ics, box, st, rank, world, local_rank, None, None)
+            bh[f"{tree}_tree"] = bh_record(args, n, tree, e2, s2)
+        if rank == 0:
+            result["bh"] = bh
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             orc = graft.load_oracle()
             result["cpu_baseline"] = cpu_baseline(orc, ics, st, box, args.workload)
+            if "bh" in result and args.workload == "bf":
+                result["bh"]["cpu_baseline"] = cpu_baseline(orc, ics, st, box, "bh")
         else:
             result["cpu_baseline"] = None
         line = json.dumps(result)

@@ -91,7 +91,7 @@ void launch_bf_cross(hipStream_t s, const Shard& sh, const CrossPlan& p, const i
 
 // K5: BarnesHutSimulation::calc_force (barnes_hut.rs:185-203) over a linearised octree
 struct TreeDev {
-    const float4* nodes = nullptr;   // 2 per node: {com.x, com.y, com.z, mass}, {width^2, skip (int bits), width, leaf body}
+    const float4* nodes = nullptr;   // 2 per node: {com.x, com.y, com.z, mass}, {width^2, skip (int bits), hot score (int bits), leaf body}
     int n_nodes = 0;
     const int* order = nullptr;      // own bodies (index into the own segment) in tree order
     int n_order = 0;
@@ -106,6 +106,13 @@ struct TreeDev {
     // reference's nested sums (k_bh_walk_nested); [NBODY_MAX_TREE_DEPTH + 1][nested_stride]
     float4* nested_stack = nullptr;
     size_t nested_stride = 0;
+    // fast math: the walk with the most-visited node records staged in LDS (k_bh_walk_lds); hot_cap = 0: off
+    float4* walk = nullptr;          // [n_nodes + 1] records with explicit links {w^2, skip link, open link, pre-order index}
+    float4* hot = nullptr;           // [hot_cap] the records every workgroup copies into its LDS
+    int* unified = nullptr;          // [n_nodes + 1] pre-order index -> link value (< hot_cap: LDS slot, else index + hot_cap)
+    int* hot_info = nullptr;         // [0] slot counter of the pass under way, [1] nodes the last pass flagged
+    int hot_cap = 0;                 // LDS table entries
+    int hot_threshold = 0;           // a node is staged if NodeB::hot >= this
 };
 // device-side octree build (kernels_tree.hip)
 struct TreeDevWork {  // arrays of the last build the split-point kernel needs

@@ -11,8 +11,9 @@
 //   * each step evaluates IPT pairs per lane and updates both sides: 16 VALU + 1 v_rsq_f32 per
 //     unordered pair (= 2 directed interactions), written stage by stage over the IPT pairs so
 //     that no instruction waits for its predecessor.
-// Measured on MI355X (tools/sym_cycles.py, in-kernel stamps): 388 SIMD cycles per 8-pair step at
-// 2.37 GHz = 128 x 2.2 (fp32 VALU) + 8 x 13 (v_rsq_f32): the kernel is fp32-issue bound.
+// Measured on MI355X (tools/sym_cycles.py, in-kernel stamps), packed form (the default): 313 SIMD
+// cycles per 8-pair step at the 2.06 GHz the chip holds under v_pk_* = 64 packed x ~4.3 + 8 x ~8
+// (v_rsq_f32); the scalar form (NBODY_SYM_PACKED=0) takes 388 at 2.37 GHz.  fp32-issue bound either way.
 //
 // Decomposition (balanced by construction): with A resident sets, set a meets the chunks of sets
 // a+1 .. a+ceil(A/2)-1 (cyclic) symmetrically (k_bf_sym); the pairs inside a set and, for even

@@ -9,9 +9,10 @@
 //                                     which is the reference's "leaf that fails the test adds 0")
 // Every lane evaluates exactly the opening tests the reference evaluates for its body, in the
 // same order and with the same rounding (r2 = (x*x + y*y) + z*z, no contraction), so the
-// accepted-node and visited-node counts equal the reference's.  Accepted monopoles are added
-// into one running sum; the reference nests the sums per tree level, which differs by rounding
-// only (tolerance in tests/test_bh_gpu.py).
+// accepted-node and visited-node counts equal the reference's.  The fast walk (k_bh_walk) adds the
+// accepted monopoles into one running sum per lane; the reference nests the sums per tree level, so
+// fast math agrees to rounding (tolerance in tests/test_bh_gpu.py).  Strict math runs
+// k_bh_walk_nested, which reproduces the nesting: accelerations bit-equal to the oracle's.
 //
 // Bodies are walked in tree (depth-first leaf) order, so the 64 lanes of a wave hold spatial
 // neighbours and follow nearly the same path: their node reads coalesce into a few 32-byte
@@ -41,6 +42,7 @@ struct WalkSplit {
     const int* n_anc;        // [n_seg]
     float4* planes;          // [n_seg][plane_stride] partial accelerations (n_seg > 1)
     size_t plane_stride;
+    int diag_first;          // k_bh_walk: segments of a body group in order of distance from its own place in the tree
 };
 constexpr int kMaxAnc = 192;
 
@@ -71,7 +73,19 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
                                                         float g, float eps2, float theta2,
                                                         unsigned long long* __restrict__ counters, WalkSplit split) {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
-    const int seg = blockIdx.y;
+    // Which of the K segments: the launch lasts as long as its slowest wave, and a body group's long walks are
+    // in the segments around its own place in the tree (that is where cells are opened down to the leaves).
+    // Bodies are in tree order, so group x of X sits near node x/X * n_nodes: the segments are taken by
+    // distance from that "diagonal" -- blockIdx.y = 0 is the group's own segment, then +1, -1, +2, ... -- and
+    // the dispatcher, which hands out workgroups in blockIdx order (x fastest), starts the heavy ones first.
+    int seg = blockIdx.y;
+    if (split.diag_first) {
+        const int K = gridDim.y;
+        const int diag = int((long long)blockIdx.x * K / gridDim.x);
+        const int kk = blockIdx.y;
+        const int off = (kk & 1) ? (kk + 1) / 2 : -(kk / 2);
+        seg = ((diag + off) % K + K) % K;
+    }
     const int s1 = split.first[seg + 1];
     unsigned int n_acc = 0, n_vis = 0;
     unsigned long long r_beg = 0;
@@ -392,13 +406,132 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_nested(const NodeDev* __
     }
 }
 
+
+// ---- Variant 3: the most-visited node records staged in LDS (north_star's "cell list staged in LDS").
+// tools/bh_visit_hist.py: at N = 65 536, theta = 0.5 the walks evaluate 1.2e8 opening tests on 97 179 nodes, and
+// the ~2 500 nodes whose grandparent cell holds >= 1 024 bodies take 70 % of them.  tools/microbench_gather.hip:
+// a CU sustains 0.675 dependent 2 x 16-byte gathers per cycle from L1/L2 with divergent lanes (k_bh_walk runs
+// at ~0.6), 1.03 from LDS, and 1.2-1.3 when half to two thirds of them go to LDS and the rest to L1 -- the two
+// pipes work side by side.
+//
+// Staged nodes are not a prefix of the pre-order array, so the walk array carries explicit links:
+//   record = {com, mass | w^2, link taken when the node is accepted (its skip), link taken when it is opened
+//             (its first child; for a leaf the same as the skip link), the node's pre-order index}
+//   link < M: slot of the LDS table; otherwise pre-order index + M in the walk array.
+// The pre-order index only decides where a segment of the node-range split ends (see WalkSplit); a sentinel
+// record behind the last node ends the last one.  The visits, their order and therefore the counters and
+// the per-segment sums are those of k_bh_walk; only where a record is read from differs.
+__global__ __launch_bounds__(256) void k_walk_slots(const NodeDev* __restrict__ nodes, int n_nodes, int threshold, int M,
+                                                    int* __restrict__ unified, int* __restrict__ info) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i > n_nodes) return;
+    int u = i + M;
+    if (i < n_nodes && __float_as_int(nodes[i].b.z) >= threshold) {
+        const int s = atomicAdd(info, 1);   // which of the flagged nodes get a slot when there are more than M is
+        if (s < M) u = s;                   // left to chance: the results do not depend on where a record lives
+    }
+    unified[i] = u;
+}
+
+__global__ __launch_bounds__(256) void k_walk_links(const NodeDev* __restrict__ nodes, int n_nodes, int M,
+                                                    const int* __restrict__ unified, NodeDev* __restrict__ walk,
+                                                    NodeDev* __restrict__ hot, int* __restrict__ info) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { info[1] = info[0]; info[0] = 0; }   // flagged count for the host's threshold control; counter reset for the next pass
+    if (i > n_nodes) return;
+    NodeDev r;
+    if (i == n_nodes) {   // sentinel: pre-order index n_nodes ends every segment
+        const float self = __int_as_float(n_nodes + M);
+        r.a = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.b = make_float4(0.f, self, self, __int_as_float(n_nodes));
+    } else {
+        r = nodes[i];
+        const int skip = __float_as_int(r.b.y);
+        r.b = make_float4(r.b.x, __int_as_float(unified[skip]), __int_as_float(unified[i + 1]), __int_as_float(i));
+    }
+    walk[i] = r;
+    const int u = unified[i];
+    if (u < M) hot[u] = r;
+}
+
+template <bool DIRECT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_bh_walk_lds(const NodeDev* __restrict__ nodes, const NodeDev* __restrict__ walk,
+                                                       const NodeDev* __restrict__ hot, int M,
+                                                       const int* __restrict__ unified, const int* __restrict__ order,
+                                                       int n_order, const float4* __restrict__ own_pos,
+                                                       float4* __restrict__ acc, float g, float eps2, float theta2,
+                                                       unsigned long long* __restrict__ counters, WalkSplit split) {
+    extern __shared__ float4 lds[];   // [2 * M]: the staged records
+    for (int k = threadIdx.x; k < 2 * M; k += BLOCK) lds[k] = reinterpret_cast<const float4*>(hot)[k];
+    __syncthreads();
+    // a workgroup's waves: consecutive (body group, segment) pairs, segment fastest -- a body group's K segments
+    // sit on one CU (equal work per CU, as in k_bh_walk's grid)
+    const int wv = blockIdx.x * (BLOCK / 64) + int(threadIdx.x >> 6);
+    const int grp = wv / split.n_seg, seg = wv - grp * split.n_seg;
+    const int t = grp * 64 + int(threadIdx.x & 63);
+    unsigned int n_acc = 0, n_vis = 0;
+    if (t < n_order) {
+        const int s1 = split.first[seg + 1];
+        const int b = order[t];
+        const float4 p = own_pos[b];
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        int u = unified[walk_entry<DIRECT>(nodes, split, seg, p, theta2)];
+        const NodeDev* __restrict__ wbase = walk - M;   // indexable by link value
+        while (true) {
+            float4 A, B;
+            if (u < M) { A = lds[2 * u]; B = lds[2 * u + 1]; }
+            else { A = wbase[u].a; B = wbase[u].b; }
+            asm volatile("" :: "v"(A.w), "v"(B.y), "v"(B.z));   // both 16-byte loads whole, ahead of the branches (see k_bh_walk)
+            if (__float_as_int(B.w) >= s1) break;
+            const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
+            const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
+            ++n_vis;
+            const int l_skip = __float_as_int(B.y), l_open = __float_as_int(B.z);
+            if (DIRECT) {
+                if (r2 < 1e-10f) { u = l_skip; continue; }                      // llm :933-935
+                if (B.x < theta2 * r2 || l_open == l_skip) {                    // llm :938 accepted cell, :958-972 leaf
+                    const float rinv = __builtin_amdgcn_rsqf(r2 + eps2);
+                    const float k = (g * A.w) * ((rinv * rinv) * rinv);
+                    ax += rx * k; ay += ry * k; az += rz * k;
+                    ++n_acc;
+                    u = l_skip;
+                } else {
+                    u = l_open;
+                }
+                continue;
+            }
+            if (B.x < theta2 * r2) {                                            // :192
+                const float rinv = __builtin_amdgcn_rsqf(r2 + eps2);
+                const float k = (g * A.w) * ((rinv * rinv) * rinv);
+                ax += rx * k; ay += ry * k; az += rz * k;
+                ++n_acc;
+                u = l_skip;
+            } else {
+                u = l_open;
+            }
+        }
+        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_acc += __shfl_down(n_acc, off);
+        n_vis += __shfl_down(n_vis, off);
+    }
+    if ((threadIdx.x & 63) == 0 && counters) {
+        const unsigned slot = unsigned(wv) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
+    }
+}
+
 }  // namespace nbody
 extern "C" int nbody_bh_walk_debug = 0;    // 1: per-wave start/end stamps (tools/bh_wave_times.py)
 extern "C" int nbody_bh_read_stamps(unsigned long long* out, int n_waves) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbody::nbody_bh_stamps), sizeof(unsigned long long) * 3 * n_waves) == hipSuccess ? 0 : -1;
 }
 extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group: 0 = automatic
-extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative, 2 = two lanes per body
+extern "C" int nbody_bh_walk_order = 1;    // 1: a group's segments are dispatched nearest-first (heaviest first), 0: in index order
+extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative, 2 = two lanes per body, 3 = hot records in LDS
+extern "C" int nbody_bh_walk_lds_block = 1024;  // variant 3: threads per workgroup (they share one LDS table)
 namespace nbody {
 
 // KICK: integrate_after_force (shared.rs:141-148) rides along, as in k_bf_sym_reduce
@@ -442,9 +575,30 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     WalkSplit sp;
     sp.n_seg = t.n_split; sp.first = t.split_first; sp.anc = t.split_anc; sp.n_anc = t.split_n_anc;
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
+    sp.diag_first = nbody_bh_walk_order;
     dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
+    if (fast_math && nbody_bh_walk_variant == 3 && t.hot_cap > 0 && t.walk) {
+        const int M = t.hot_cap;
+        const dim3 pg((t.n_nodes + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_walk_slots, pg, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.hot_threshold, M, t.unified, t.hot_info);
+        hipLaunchKernelGGL(k_walk_links, pg, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, M, t.unified,
+                           reinterpret_cast<NodeDev*>(t.walk), reinterpret_cast<NodeDev*>(t.hot), t.hot_info);
+        const int groups = (t.n_order + 63) / 64;
+        const long long waves = (long long)groups * t.n_split;
+        const size_t lds_bytes = size_t(M) * sizeof(NodeDev);
+#define WALK_LDS(DIRECT, BLK) do {                                                                                          \
+            static bool attr_set = false;                                                                                   \
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bh_walk_lds<DIRECT, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+            hipLaunchKernelGGL((k_bh_walk_lds<DIRECT, BLK>), dim3(unsigned((waves + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), lds_bytes, s,   \
+                               reinterpret_cast<const NodeDev*>(t.nodes), reinterpret_cast<const NodeDev*>(t.walk),         \
+                               reinterpret_cast<const NodeDev*>(t.hot), M, t.unified, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp); } while (0)
+        if (nbody_bh_walk_lds_block == 512) { if (leaf_direct) WALK_LDS(true, 512); else WALK_LDS(false, 512); }
+        else if (nbody_bh_walk_lds_block == 256) { if (leaf_direct) WALK_LDS(true, 256); else WALK_LDS(false, 256); }
+        else { if (leaf_direct) WALK_LDS(true, 1024); else WALK_LDS(false, 1024); }
+#undef WALK_LDS
+    } else {
     // the alternative walks are fast-math experiments with the reference leaf rule only
-    const int variant = (leaf_direct || !fast_math) ? 0 : nbody_bh_walk_variant;
+    const int variant = (leaf_direct || !fast_math) ? 0 : (nbody_bh_walk_variant == 3 ? 0 : nbody_bh_walk_variant);
     if (variant == 2) grid.x = (2 * t.n_order + kWalkBlock - 1) / kWalkBlock;
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
     if (variant == 1) WALK(k_bh_walk_wave, true);
@@ -462,6 +616,7 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     else if (nbody_bh_walk_debug && fast_math) WALK(k_bh_walk, true, false, true);
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
+    }
     if (t.n_split > 1) {
         const dim3 rg((t.n_order + 255) / 256);
         if (kick_dt) {

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
         if (idx == 0) {
             if (node_cap >= 1) {
                 nodes[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                nodes[1] = make_float4(width * width, __int_as_float(1), width, __int_as_float(-1));
+                nodes[1] = make_float4(width * width, __int_as_float(1), __int_as_float(0), __int_as_float(-1));
             }
             out_info[0] = 1;
             out_info[2] = 0;
@@ -129,9 +129,22 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
     const int d_prev = (k > 0) ? delta[k - 1] : -1;
     const int opened = max(0, d_next - d_prev);
     const int t = idx - base[k];
+    const unsigned long long key = keys[k];
+    // NodeB::hot (octree_host.h): bodies in the grandparent cell = sorted bodies sharing the first depth-2 levels
+    const int my_depth = (t < opened) ? d_prev + 1 + t : max(d_prev, d_next) + 1;
+    int hot = n;
+    if (my_depth >= 2) {
+        const int sh = 3 * (kLevels - (my_depth - 2));
+        const unsigned long long lo_key = (key >> sh) << sh, hi_gp = lo_key | ((1ull << sh) - 1ull);
+        int a = 0, b = k;               // first sorted body with key >= lo_key
+        while (a < b) { const int mid = (a + b) >> 1; if (keys[mid] >= lo_key) b = mid; else a = mid + 1; }
+        const int first = a;
+        a = k; b = n - 1;               // last sorted body with key <= hi_gp
+        while (a < b) { const int mid = (a + b + 1) >> 1; if (keys[mid] <= hi_gp) a = mid; else b = mid - 1; }
+        hot = a - first + 1;
+    }
     if (t < opened) {                   // a cell this body opens, shallowest first
         const int d = d_prev + 1 + t;   // depth of the cell: its bodies share d levels
-        const unsigned long long key = keys[k];
         const int shift = 3 * (kLevels - d);
         const unsigned long long hi_key = key | ((shift >= 64) ? ~0ull : ((1ull << shift) - 1ull));
         int a = k, b = n - 1;           // last sorted body with key <= hi_key
@@ -148,14 +161,14 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
         const int skip = (j + 1 < n) ? base[j + 1] : total;
         nodes[2 * idx] = make_float4(float((upto.x - before.x) / m), float((upto.y - before.y) / m),
                                      float((upto.z - before.z) / m), float(m));
-        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(skip), w, __int_as_float(-1));
+        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(skip), __int_as_float(hot), __int_as_float(-1));
     } else {                            // the body's leaf
         const int ld = max(d_prev, d_next) + 1;
         float w = width;
         for (int q = 0; q < ld; ++q) w = w * 0.5f;
         const int id = ids[k];
         nodes[2 * idx] = pos[id];
-        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(idx + 1), w, __int_as_float(id));
+        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(idx + 1), __int_as_float(hot), __int_as_float(id));
         order[k] = id;
     }
 }

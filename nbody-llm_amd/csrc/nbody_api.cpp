@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +29,8 @@ extern "C" int nbody_sym_rounds;
 extern "C" int nbody_sym_packed;
 extern "C" int nbody_bh_walk_split;
 extern "C" int nbody_bh_walk_variant;
+extern "C" int nbody_bh_walk_lds_block;
+extern "C" int nbody_bh_hot_cap = 2048;  // fast walk, variant 3: node records staged in LDS per workgroup (32 B each)
 extern "C" int nbody_cross_sym = 1;  // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided
 
 using nbody::BoundsF;
@@ -76,6 +79,16 @@ struct NbodyHandle {
     int* h_split = nullptr;      // pinned mirror
     float4* d_walk_planes = nullptr;
     size_t walk_planes_cap = 0;  // float4 entries
+    // fast walk with the most-visited records in LDS (kernels_bh.hip, variant 3)
+    float4* d_walk = nullptr;    // [walk_cap + 1] records with explicit links
+    int* d_unified = nullptr;    // [walk_cap + 1]
+    size_t walk_cap = 0;         // nodes
+    float4* d_hot = nullptr;     // [hot_cap] records
+    int hot_cap = 0;
+    int* d_hot_info = nullptr;   // [2] slot counter, nodes flagged by the last pass
+    int* h_hot_info = nullptr;   // pinned; refreshed after every walk, read after the next step's first sync
+    int hot_threshold = 0;       // NodeB::hot >= this -> staged; steered so that ~hot_cap nodes qualify
+    size_t hot_threshold_n = 0;  // body count the threshold was initialised for
     unsigned long long* d_counters = nullptr;  // [NBODY_WALK_COUNTER_SLOTS][2] accepted, visited (summed on read)
     unsigned long long* h_counters = nullptr;  // pinned
 
@@ -263,11 +276,11 @@ constexpr size_t kShardedSymMinBodies = 2048; // sharded: own-own symmetric + re
 
 // (re)build the symmetric kernel's plan when the number of resident sets changes
 int ensure_sym_plan(NbodyHandle* h) {
-    const int A = int((h->n_local + 511) / 512);
+    const int A = int((std::max<size_t>(1, h->n_local) + 511) / 512);  // (an empty shard still plans one set)
     const int knobs = nbody_sym_wpb * 100 + nbody_sym_rounds;
     if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == knobs) return NBODY_OK;
     h->sym_waves = knobs;
-    h->sym_plan = nbody::make_sym_plan(int(h->n_local));
+    h->sym_plan = nbody::make_sym_plan(int(std::max<size_t>(1, h->n_local)));
     nbody::SymPlan& p = h->sym_plan;
     h->cross_on = false;
     if (h->sh.n_seg > 1) {
@@ -276,7 +289,7 @@ int ensure_sym_plan(NbodyHandle* h) {
         if (nbody_cross_sym && h->sh.n_seg <= 2 * (nbody::CrossPartners::kMax - 1)) {
             // every unordered pair between shards once: this GPU is resident for some partners and
             // receives the partial sums the others accumulated for its bodies
-            h->cross = nbody::make_cross_plan(h->sh.my_seg, h->sh.n_seg, h->sh.seg_cap, int(h->n_local));
+            h->cross = nbody::make_cross_plan(h->sh.my_seg, h->sh.n_seg, h->sh.seg_cap, int(std::max<size_t>(1, h->n_local)));
             h->cross_on = true;
             h->recv_plane0 = p.n_planes + h->cross.k_res;
             p.n_planes += h->cross.k_res + h->cross.n_recv;
@@ -329,7 +342,10 @@ int bf_forces(NbodyHandle* h) {
     const float eps2 = h->g_soft * h->g_soft;  // brute_force.rs:69
     const bool fast = h->cfg.math_mode == NBODY_MATH_FAST && nbody_bf_fast_variant == 0;
     const bool sharded = h->sh.n_seg > 1;
-    const bool sym = fast && h->n_local >= (sharded ? kShardedSymMinBodies : kSymMinBodies);
+    // Sharded: decided from the shard CAPACITY, which every rank shares.  The live counts differ from rank
+    // to rank (ragged last block, bodies leaving the box), and a rank that chose another scheme than its
+    // peers would neither send nor expect the partial sums the others exchange with it (a hang in RCCL).
+    const bool sym = fast && (sharded ? size_t(h->sh.seg_cap) >= kShardedSymMinBodies : h->n_local >= kSymMinBodies);
     const size_t tot = total_upper(h);
     if (sym) {
         int rc = ensure_sym_plan(h);
@@ -434,6 +450,47 @@ int ensure_nested_stack(NbodyHandle* h, nbody::TreeDev* td) {
     return NBODY_OK;
 }
 
+// fast math, variant 3: buffers of the LDS-staged walk and the threshold that picks the staged nodes.
+// Called after this step's first host synchronisation, so h_hot_info holds the previous pass's flagged count.
+int setup_lds_walk(NbodyHandle* h, nbody::TreeDev* td, size_t n_tree) {
+    if (h->cfg.math_mode != NBODY_MATH_FAST || nbody_bh_walk_variant != 3 || nbody_bh_hot_cap <= 0) return NBODY_OK;
+    const int M = std::min(nbody_bh_hot_cap, 5000);  // 160 KB of LDS per CU, 32 B per record
+    if (h->walk_cap < h->d_node_cap) {
+        if (h->d_walk) (void)hipFree(h->d_walk);
+        if (h->d_unified) (void)hipFree(h->d_unified);
+        h->d_walk = nullptr; h->d_unified = nullptr; h->walk_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_walk, (h->d_node_cap + 1) * 2 * sizeof(float4)));
+        HIP_TRY(h, hipMalloc(&h->d_unified, (h->d_node_cap + 1) * sizeof(int)));
+        h->walk_cap = h->d_node_cap;
+    }
+    if (h->hot_cap != M) {
+        if (h->d_hot) (void)hipFree(h->d_hot);
+        h->d_hot = nullptr; h->hot_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_hot, size_t(M) * 2 * sizeof(float4)));
+        HIP_TRY(h, hipMemsetAsync(h->d_hot, 0, size_t(M) * 2 * sizeof(float4), h->stream));
+        h->hot_cap = M;
+        h->hot_threshold_n = 0;
+    }
+    if (!h->d_hot_info) {
+        HIP_TRY(h, hipMalloc(&h->d_hot_info, 2 * sizeof(int)));
+        HIP_TRY(h, hipMemsetAsync(h->d_hot_info, 0, 2 * sizeof(int), h->stream));
+        HIP_TRY(h, hipHostMalloc(&h->h_hot_info, 2 * sizeof(int), hipHostMallocDefault));
+        h->h_hot_info[0] = h->h_hot_info[1] = 0;
+    }
+    if (h->hot_threshold_n == 0 || n_tree > 2 * h->hot_threshold_n || 2 * n_tree < h->hot_threshold_n) {
+        // first guess: the grandparent holds 1/64 of the bodies (2 500 nodes at N = 65 536 Plummer)
+        h->hot_threshold = int(std::max<size_t>(8, n_tree / 64));
+        h->hot_threshold_n = std::max<size_t>(1, n_tree);
+    } else {
+        const int flagged = h->h_hot_info[1];
+        if (flagged > M) h->hot_threshold = h->hot_threshold + h->hot_threshold / 8 + 1;
+        else if (flagged < M - M / 3 && h->hot_threshold > 2) h->hot_threshold = h->hot_threshold - h->hot_threshold / 8 - 1;
+    }
+    td->walk = h->d_walk; td->unified = h->d_unified; td->hot = h->d_hot; td->hot_info = h->d_hot_info;
+    td->hot_cap = M; td->hot_threshold = h->hot_threshold;
+    return NBODY_OK;
+}
+
 int bh_forces(NbodyHandle* h) {
     Shard& sh = h->sh;
     {
@@ -495,8 +552,11 @@ int bh_forces(NbodyHandle* h) {
     // split the node range over several waves per body group when there are too few bodies to fill
     // the chip (>= 8 waves per SIMD wanted: the walk is bound by the latency of dependent loads)
     {
-        constexpr int kMaxSplit = 32, kMaxAnc = 192;
-        int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((8192 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+        constexpr int kMaxSplit = 64, kMaxAnc = 192;
+        // ~3 waves per wave slot of the chip (256 CUs x 32), handed out heaviest first (nbody_bh_walk_order): the launch
+        // lasts as long as its slowest wave, and smaller pieces started in the right order shorten that tail
+        // (N = 65 536: 24 segments 0.310 ms, 8 segments 0.336 ms; tools/tune_bh_order.py)
+        int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((24576 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
         K = std::max(1, std::min(kMaxSplit, K));
         // strict math is the parity path: one segment, so every lane adds in the reference's order (bit-exact)
         if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;
@@ -554,6 +614,8 @@ int bh_forces(NbodyHandle* h) {
     {
         int rc_ns = ensure_nested_stack(h, &td);
         if (rc_ns) return rc_ns;
+        rc_ns = setup_lds_walk(h, &td, h->tree.n_order);
+        if (rc_ns) return rc_ns;
     }
     {
         ForceTimer t(h);
@@ -563,6 +625,7 @@ int bh_forces(NbodyHandle* h) {
                               h->kick_pending ? &h->kick_dt : nullptr, &kicked);
         if (kicked) h->kick_pending = false;  // the plane reduction applied the kick + half drift
     }
+    if (td.hot_cap > 0) HIP_TRY(h, hipMemcpyAsync(h->h_hot_info, h->d_hot_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
@@ -633,12 +696,12 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     h->tree_on_device = true;
     h->tree.n_nodes = size_t(n_nodes);  // (the host copy is filled on demand by nbody_tree_export)
 
-    constexpr int kMaxSplit = 32, kMaxAnc = 192;
+    constexpr int kMaxSplit = 64, kMaxAnc = 192;
     if (!h->d_split) {
         HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
         HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
     }
-    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((8192 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((24576 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
     K = std::max(1, std::min(kMaxSplit, K));
     if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
     while (K > 1 && K * 16 > n_nodes) K /= 2;
@@ -667,6 +730,8 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     {
         int rc_ns = ensure_nested_stack(h, &td);
         if (rc_ns) return rc_ns;
+        rc_ns = setup_lds_walk(h, &td, n_tree);
+        if (rc_ns) return rc_ns;
     }
     {
         ForceTimer t(h);
@@ -676,6 +741,7 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
                               h->kick_pending ? &h->kick_dt : nullptr, &kicked);
         if (kicked) h->kick_pending = false;  // the plane reduction applied the kick + half drift
     }
+    if (td.hot_cap > 0) HIP_TRY(h, hipMemcpyAsync(h->h_hot_info, h->d_hot_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
@@ -800,9 +866,9 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
+                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_walk, h->d_unified, h->d_hot, h->d_hot_info, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info};
+    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info, h->h_hot_info};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -879,6 +945,8 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (const char* v = std::getenv("NBODY_SYM_PACKED")) nbody_sym_packed = std::atoi(v);
     if (const char* v = std::getenv("NBODY_BH_VARIANT")) nbody_bh_walk_variant = std::atoi(v);
     if (const char* v = std::getenv("NBODY_BH_SPLIT")) nbody_bh_walk_split = std::atoi(v);
+    if (const char* v = std::getenv("NBODY_BH_HOT")) nbody_bh_hot_cap = std::atoi(v);
+    if (const char* v = std::getenv("NBODY_BH_LDS_BLOCK")) nbody_bh_walk_lds_block = std::atoi(v);
     if (const char* v = std::getenv("NBODY_SYM_WPB")) nbody_sym_wpb = std::atoi(v);
     *out = h;
     return NBODY_OK;
@@ -1208,7 +1276,7 @@ int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* sk
     for (size_t i = 0; i < n; ++i) {
         const nbody::NodeRec& r = h->tree.nodes[i];
         if (com_mass) { com_mass[4 * i] = r.a.x; com_mass[4 * i + 1] = r.a.y; com_mass[4 * i + 2] = r.a.z; com_mass[4 * i + 3] = r.a.m; }
-        if (width) width[i] = r.b.w;
+        if (width) width[i] = std::sqrt(r.b.w2);  // exact: w2 is the rounded square of the width
         if (skip) skip[i] = r.b.skip;
     }
     return NBODY_OK;
@@ -1353,7 +1421,7 @@ int nbody_host_build_tree(const float* pos4, size_t n, const float center[3], fl
     for (size_t i = 0; i < tree.n_nodes; ++i) {
         const nbody::NodeRec& r = tree.nodes[i];
         com_mass[4 * i] = r.a.x; com_mass[4 * i + 1] = r.a.y; com_mass[4 * i + 2] = r.a.z; com_mass[4 * i + 3] = r.a.m;
-        if (node_width) node_width[i] = r.b.w;
+        if (node_width) node_width[i] = std::sqrt(r.b.w2);
         if (skip) skip[i] = r.b.skip;
         if (leaf_body) leaf_body[i] = r.b.body;
     }

@@ -264,9 +264,10 @@ inline void scatter(const Item* src, Item* dst, const uint8_t* code, int n, cons
     for (int k = 0; k < n; ++k) dst[off[code[k]]++] = src[k];
 }
 
-void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int depth, Emit& e) {
+// pn, gpn: bodies in the parent and grandparent cells (NodeB::hot)
+void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int depth, Emit& e, int pn, int gpn) {
     const int me = int(e.nodes.size());
-    e.nodes.push_back(NodeRec{NodeA{0.f, 0.f, 0.f, 0.f}, NodeB{box.w * box.w, me + 1, box.w, -1}});
+    e.nodes.push_back(NodeRec{NodeA{0.f, 0.f, 0.f, 0.f}, NodeB{box.w * box.w, me + 1, gpn, -1}});
     if (n == 0) return;
     if (n == 1) {
         e.nodes[me].a = NodeA{src[0].x, src[0].y, src[0].z, src[0].m};
@@ -280,14 +281,14 @@ void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
     classify_and_sum(src, code, n, box, cnt, node);
     scatter(src, tmp, code, n, cnt, start);
     for (int o = 0; o < 8; ++o)
-        if (cnt[o]) build_rec(tmp + start[o], src + start[o], code + start[o], cnt[o], box.child(o), depth + 1, e);
+        if (cnt[o]) build_rec(tmp + start[o], src + start[o], code + start[o], cnt[o], box.child(o), depth + 1, e, n, pn);
     e.nodes[me].a = node;
     e.nodes[me].b.skip = int(e.nodes.size());
 }
 
 constexpr int kTaskDepth = 2;
 
-struct Task { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; Emit* out; };
+struct Task { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; Emit* out; int pn, gpn; };
 
 struct TopEntry {
     int task = -1;   // >= 0: the subtree built by that task; else a node of the top levels
@@ -297,10 +298,10 @@ struct TopEntry {
 };
 
 void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int depth, std::vector<TopEntry>& top,
-               std::vector<Task>& tasks) {
+               std::vector<Task>& tasks, int pn, int gpn) {
     const int me = int(top.size());
     top.emplace_back();
-    top[me].b = NodeB{box.w * box.w, 0, box.w, -1};
+    top[me].b = NodeB{box.w * box.w, 0, gpn, -1};
     if (n == 0) { top[me].end = me + 1; return; }
     if (n == 1) {
         top[me].a = NodeA{src[0].x, src[0].y, src[0].z, src[0].m};
@@ -311,7 +312,7 @@ void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
     if (depth >= kTaskDepth) {
         top[me].task = int(tasks.size());
         top[me].end = me + 1;
-        tasks.push_back(Task{src, tmp, code, n, box, depth, nullptr});
+        tasks.push_back(Task{src, tmp, code, n, box, depth, nullptr, pn, gpn});
         return;
     }
     int cnt[8], start[8];
@@ -319,7 +320,7 @@ void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
     classify_and_sum(src, code, n, box, cnt, node);
     scatter(src, tmp, code, n, cnt, start);
     for (int o = 0; o < 8; ++o)
-        if (cnt[o]) build_top(tmp + start[o], src + start[o], code + start[o], cnt[o], box.child(o), depth + 1, top, tasks);
+        if (cnt[o]) build_top(tmp + start[o], src + start[o], code + start[o], cnt[o], box.child(o), depth + 1, top, tasks, n, pn);
     top[me].a = node;
     top[me].end = int(top.size());
 }
@@ -380,17 +381,17 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
     std::vector<Task> tasks;
     if (n < 8192 || T == 1) {
         fill(0, n);
-        build_top(A, B, C, int(n), root, 0, top, tasks);
+        build_top(A, B, C, int(n), root, 0, top, tasks, int(n), int(n));
     } else {
         // ---- big nodes (more than `big` bodies) are partitioned level by level with every thread
         // working on chunks of them; their folds (mass, com: sequential, the reference's order) run
         // as separate tasks beside the chunk work.  Everything smaller becomes a subtree task.
         // Depth alone is a poor cut: a Plummer sphere in a wide box keeps most bodies in 8 cells
         // per level for several levels.
-        struct Big { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; int self; };
+        struct Big { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; int self; int pn; };  // pn: bodies in the parent cell
         struct TNode { NodeA a{}; NodeB b{}; int child[8]; int task = -1; };
         std::vector<TNode> tn;
-        auto new_tnode = [&](const Box& bx) { TNode t; t.b = NodeB{bx.w * bx.w, 0, bx.w, -1}; for (int& c : t.child) c = -1; tn.push_back(t); return int(tn.size()) - 1; };
+        auto new_tnode = [&](const Box& bx, int hot) { TNode t; t.b = NodeB{bx.w * bx.w, 0, hot, -1}; for (int& c : t.child) c = -1; tn.push_back(t); return int(tn.size()) - 1; };
         const int big = std::max(2048, int(n / 64));
         const int chunk = std::max(1024, big / 2);
         // the root's fold is a 4 x n-long dependent chain (~50 us at n = 65 536) nobody needs before the
@@ -408,7 +409,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         pool.post_background(fold_root);
         pool.run(T, [&](int t) { const size_t c = (n + T - 1) / T; fill(std::min(n, size_t(t) * c), std::min(n, size_t(t + 1) * c)); });
         lap("fill");
-        std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root)}};
+        std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root, int(n)), int(n)}};
         struct Piece { int node; int k0, k1; };
         while (!level.empty()) {
             std::vector<Piece> pieces;
@@ -457,7 +458,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
                     const int cn = ntot[b][o];
                     if (!cn) continue;
                     const Box cb = g.box.child(o);
-                    const int id = new_tnode(cb);
+                    const int id = new_tnode(cb, g.pn);  // the child's grandparent is g's parent
                     tn[g.self].child[o] = id;
                     Item* csrc = g.tmp + nstart[b][o];
                     Item* ctmp = g.src + nstart[b][o];
@@ -466,10 +467,10 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
                         tn[id].a = NodeA{csrc[0].x, csrc[0].y, csrc[0].z, csrc[0].m};
                         tn[id].b.body = csrc[0].id;
                     } else if (cn > big && g.depth + 1 < 24) {
-                        next.push_back(Big{csrc, ctmp, ccode, cn, cb, g.depth + 1, id});
+                        next.push_back(Big{csrc, ctmp, ccode, cn, cb, g.depth + 1, id, g.n});
                     } else {
                         tn[id].task = int(tasks.size());
-                        tasks.push_back(Task{csrc, ctmp, ccode, cn, cb, g.depth + 1, nullptr});
+                        tasks.push_back(Task{csrc, ctmp, ccode, cn, cb, g.depth + 1, nullptr, g.n, g.pn});
                     }
                 }
             }
@@ -504,7 +505,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         Task& tk = tasks[by_size[i]];
         Emit& e = *tk.out;
         e.nodes.clear(); e.order.clear(); e.too_deep = false;
-        build_rec(tk.src, tk.tmp, tk.code, tk.n, tk.box, tk.depth, e);
+        build_rec(tk.src, tk.tmp, tk.code, tk.n, tk.box, tk.depth, e, tk.pn, tk.gpn);
     });
 
     lap("subtrees");

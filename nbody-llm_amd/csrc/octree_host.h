@@ -45,7 +45,13 @@ private:
 };
 
 struct NodeA { float x, y, z, m; };               // centre of mass, mass
-struct NodeB { float w2; int32_t skip; float w; int32_t body; };  // width^2, skip, width, body id of a leaf or -1
+// width^2, skip, "hot" = bodies in the node's GRANDPARENT cell (the root's count for depths 0 and 1), body id of
+// a leaf or -1.  The width itself is sqrt(w2), exactly (IEEE sqrt of a rounded square returns the operand).
+// hot ranks the nodes by how many walks visit them (a node is visited by the bodies that open its parent,
+// i.e. those within parent-width / theta of it: about the population around the grandparent cell); the
+// fast walk stages the highest-ranked records in LDS (kernels_bh.hip).  tools/bh_visit_hist.py: the 2 048
+// nodes ranked first by this score take 66 % of all visits at N = 65 536, the 2 048 truly hottest 67 %.
+struct NodeB { float w2; int32_t skip; int32_t hot; int32_t body; };
 struct alignas(32) NodeRec { NodeA a; NodeB b; };  // one 32-byte record per node: a single s_load_dwordx8 on the device
 
 // Output arrays live in caller-chosen memory (the API hands in pinned-host allocators so the

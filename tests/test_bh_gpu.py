@@ -184,6 +184,52 @@ def test_alternative_walk_kernels_same_nodes(gpu, orc, variant, math, n, split):
     assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
 
 
+@pytest.mark.parametrize("tree", ["host", "device"])
+@pytest.mark.parametrize("leaf", ["reference", "direct"])
+@pytest.mark.parametrize("n,split,hot,block", [(3001, 0, 2048, 1024), (777, 1, 64, 256), (20000, 4, 1024, 512),
+                                              (20000, 8, 4096, 1024), (65536, 0, 2048, 1024), (9, 0, 2048, 1024)])
+def test_lds_staged_walk_equals_the_plain_fast_walk(gpu, orc, tree, leaf, n, split, hot, block):
+    """Variant 3 (north_star's "cell list staged in LDS"): the most-visited node records live in an LDS table per
+    workgroup, the walk follows explicit links instead of pre-order index arithmetic.  It evaluates the same
+    opening tests in the same order and adds the same per-segment sums as k_bh_walk: node counts equal the
+    oracle's (host tree) and the accelerations equal the plain fast walk's BIT FOR BIT, for every table size
+    (smaller than, about, and larger than the number of flagged nodes), workgroup size, split and leaf rule.
+    Several steps, so the threshold control and the re-staging of a changed tree are exercised."""
+    import ctypes
+    nb = gpu
+    sd, st = sd_st(nb, theta2=0.25, g_soft=0.01)
+    ics = nb.plummer(n, seed=35)
+    var = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_variant")
+    spl = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    cap = ctypes.c_int.in_dll(nb.lib, "nbody_bh_hot_cap")
+    blk = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_lds_block")
+    old = (var.value, spl.value, cap.value, blk.value)
+    kw = dict(method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE if tree == "device" else nb.TREE_HOST,
+              leaf_mode=nb.LEAF_DIRECT if leaf == "direct" else nb.LEAF_REFERENCE)
+    out = {}
+    try:
+        for v in (0, 3):
+            var.value, spl.value, cap.value, blk.value = v, split, hot, block
+            with nb.Simulation(ics, *BOX, **kw) as sim:
+                sim.settings = st
+                sim.update_forces()
+                first = sim.get_points()
+                s1 = sim.stats()
+                sim.steps(4)
+                out[v] = (first, (s1.interactions, s1.node_visits), sim.get_points(), sim.stats())
+    finally:
+        var.value, spl.value, cap.value, blk.value = old
+    assert out[3][1] == out[0][1]
+    assert np.array_equal(out[3][0]["acceleration"].view(np.uint32), out[0][0]["acceleration"].view(np.uint32))
+    assert (out[3][3].interactions, out[3][3].node_visits) == (out[0][3].interactions, out[0][3].node_visits)
+    for f in ("position", "velocity", "acceleration"):
+        assert np.array_equal(out[3][2][f].view(np.uint32), out[0][2][f].view(np.uint32)), f
+    if tree == "host" and leaf == "reference" and n <= 20000:
+        ref = ics.copy().astype(orc.P32)
+        assert out[3][1] == orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4)
+        assert rel_err(out[3][0]["acceleration"], ref["acceleration"]) < 1e-5
+
+
 def test_retain_in_a_tight_box(gpu, orc):
     nb = gpu
     box = ((0.0, 0.0, 0.0), 2.0)

@@ -68,7 +68,8 @@ def test_brute_force_shards_with_escapes(gpu, orc):
 
 
 @pytest.mark.parametrize("cross", [1, 0])
-@pytest.mark.parametrize("G,n", [(2, 6000), (2, 20000), (3, 10000), (4, 9001), (5, 12000), (8, 20000), (8, 65536)])
+@pytest.mark.parametrize("G,n", [(2, 6000), (2, 20000), (3, 10000), (4, 9001), (5, 12000), (8, 20000), (8, 65536),
+                                 (2, 4095), (8, 16385)])  # ragged last block on the other side of 2048 bodies
 def test_brute_force_fast_shards(gpu, orc, G, n, cross):
     """fast math, sharded (n/G >= 2048; below that the LDS-tiled kernel): the own shard by the
     symmetric kernel; the other shards either symmetric too (cross = 1, the default: every pair
@@ -134,6 +135,32 @@ def test_brute_force_fast_shards_with_escapes(gpu, orc):
         ref = orc.bf_step_by(ref, sd, box[0], box[1], sd["dt"])
     got = gather(sims)
     assert len(ref) < 11500 and len(got) == len(ref)
+    assert np.array_equal(got["mass"], ref["mass"])
+    assert rel_err(got["position"], ref["position"]) < 1e-5
+    for s in sims:
+        s.close()
+
+
+def test_fast_shards_straddling_the_symmetric_threshold_after_escapes(gpu, orc):
+    """Shards of 2150 bodies in a tight box: bodies leave, one shard's live count falls below the 2048
+    bodies at which the symmetric scheme starts while its peer is still above, and get_points() between
+    steps refreshes every rank's host view of its own count independently.  The scheme is chosen from the
+    shard capacity (shared by all ranks), so the partial-sum exchange keeps matching."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 2.2)
+    sd = dict(g=1.0, g_soft=0.05, dt=2e-2, theta2=0.5)
+    ics = nb.plummer(4300, seed=14)
+    sims = make_world(nb, ics, 2, box, nb.Settings(**sd), nb.BRUTE_FORCE, nb.FAST)
+    ref = ics.copy().astype(orc.P32)
+    lens = []
+    for k in range(10):
+        nb.sharded_step(sims)
+        ref = orc.bf_step_by(ref, sd, box[0], box[1], sd["dt"])
+        if k % 3 == 0:
+            lens.append([len(s.get_points()) for s in sims])   # one rank at a time, as a visualiser would
+    got = gather(sims)
+    assert min(min(l) for l in lens) < 2048, lens
+    assert len(got) == len(ref)
     assert np.array_equal(got["mass"], ref["mass"])
     assert rel_err(got["position"], ref["position"]) < 1e-5
     for s in sims:
