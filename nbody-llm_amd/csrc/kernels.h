@@ -113,6 +113,10 @@ struct TreeDev {
     int* hot_info = nullptr;         // [0] slot counter of the pass under way, [1] nodes the last pass flagged
     int hot_cap = 0;                 // LDS table entries
     int hot_threshold = 0;           // a node is staged if NodeB::hot >= this
+    // fast math: the cooperative block walk (k_bh_walk_block) reads this level-order copy of `nodes`, built per step
+    float4* bfs = nullptr;           // [n_nodes] records {com, mass | w^2, pre-order index, pre-order skip, first child | last flag}
+    void* bfs_ws = nullptr;          // workspace of build_bfs_layout
+    size_t bfs_cap = 0;              // nodes both are sized for
 };
 // device-side octree build (kernels_tree.hip)
 struct TreeDevWork {  // arrays of the last build the split-point kernel needs
@@ -136,6 +140,9 @@ int launch_tree_own_order(hipStream_t s, const int* order, const TreeCat& c, int
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
                         int* out_info, TreeDevWork* work);
+// level-order copy of a pre-order node array for the cooperative block walk
+size_t bfs_workspace_bytes(size_t n_cap);
+int build_bfs_layout(hipStream_t s, const float4* nodes, int n_nodes, void* workspace, size_t n_cap, float4* out);
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
                            int* n_anc, int* anc, int max_anc);
 

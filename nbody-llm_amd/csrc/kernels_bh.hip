@@ -63,7 +63,7 @@ __device__ __forceinline__ int walk_entry(const NodeDev* __restrict__ nodes, con
     return s0;  // every ancestor was opened: the walk arrives at first[seg] itself
 }
 
-__device__ unsigned long long nbody_bh_stamps[3 * 16384];  // diagnostic build only (DBG): per wave start, end (100 MHz ticks), iterations
+__device__ unsigned long long nbody_bh_stamps[3 * 65536];  // diagnostic build only (DBG): per wave start, end (100 MHz ticks), iterations
 
 // DIRECT = NBODY_LEAF_DIRECT: the walk of src/llm/barnes_hut.rs:915-997 on the same tree (see nbody_hip.h)
 template <bool FAST, bool DIRECT = false, bool DBG = false, int BLOCK = kWalkBlock>
@@ -97,8 +97,10 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
         int i = walk_entry<DIRECT>(nodes, split, seg, p, theta2);  // first node >= s0 this body's walk visits
         while (i < s1) {
             const float4 A = nodes[i].a;
-            const float4 B = nodes[i].b;
-            // keep both 16-byte loads whole and ahead of the branch: left alone the compiler narrows them
+            // of the record's second half the walk needs {w^2, skip link} only: an 8-byte load (24 instead of 32
+            // bytes per visit through the L1's 64 B/clk return path)
+            const float2 B = *reinterpret_cast<const float2*>(&nodes[i].b);
+            // keep both loads whole and ahead of the branch: left alone the compiler narrows them
             // to {x,y,z} + {w^2} and fetches mass and skip link in a second, dependent round trip under
             // the accept branch (4 L1 accesses and two load latencies per accepted visit)
             asm volatile("" :: "v"(A.w), "v"(B.y));
@@ -407,6 +409,271 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_nested(const NodeDev* __
 }
 
 
+// ---- Variant 4: wave-cooperative walk over a window of node records in LDS.
+// The 64 lanes of a wave (64 tree-order neighbours) step through the UNION of their node sequences with a
+// wave-uniform node index; lane l takes part in node i iff i >= resume[l] (= its own walk would visit i), the wave
+// goes to i + 1 while any taking-part lane opens the node, else to the node's skip link.  tools/bh_visit_hist.py:
+// at N = 65 536, theta = 0.5 the union is 3 368 nodes per wave against 1 994 for the wave's longest single walk
+// (1 832 on average), no step without a taking-part lane -- 1.7x the iterations of the per-lane walk, but every
+// iteration reads ONE record for all lanes instead of up to 64 different ones (the per-lane walk is bound by the
+// L1's tag look-ups: 1.24 cache lines per lane-visit).  k_bh_walk_wave (variant 1) fetched that record with a scalar
+// load per iteration and was bound by its latency; here the wave keeps a WINDOW of kWin consecutive records in
+// registers (lane l: record base + l), filled by one coalesced load (2 KB) when the index leaves it (every ~6
+// iterations; the next kWin records are requested ahead), and hands the current record round with v_readlane: it
+// arrives in SGPRs, no LDS, no barrier.  (A first form kept the window in LDS and read it as a broadcast: 500
+// cycles per iteration on the longest waves, the LDS round trip and the exposed window fills.)  Per lane the accepted
+// nodes, their order, the arithmetic and the counters are those of k_bh_walk: same bits.
+constexpr int kWin = 64;
+
+__device__ __forceinline__ float lane_value(float v, int l) {   // VGPR of lane l (wave-uniform l) -> SGPR
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// walk_entry for a whole wave at once: the ancestors of the segment's first node are the same for every lane, so
+// their records are fetched by ONE gather (lane k: ancestor k) instead of a dependent chain of loads per lane
+// (measured: 5.7 us per wave, a fifth of all wave-slot time at 48 segments), then every lane replays the opening tests
+// on the records handed round with v_readlane.  Returns the first node >= first[seg] the lane's walk visits.
+template <bool DIRECT>
+__device__ __forceinline__ int walk_entry_coop(const NodeDev* __restrict__ nodes, const WalkSplit& sp, int seg,
+                                               const float4 p, float theta2, int lane) {
+    const int na = sp.n_anc[seg];
+    int res = -1;
+    for (int k0 = 0; k0 < na; k0 += 64) {
+        const int cnt = min(64, na - k0);
+        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
+        if (lane < cnt) {
+            const int j = sp.anc[seg * kMaxAnc + k0 + lane];
+            A = nodes[j].a;
+            B = nodes[j].b;
+        }
+        for (int k = 0; k < cnt; ++k) {
+            const float x = lane_value(A.x, k), y = lane_value(A.y, k), z = lane_value(A.z, k);
+            const float w2 = lane_value(B.x, k);
+            const int skip = __builtin_amdgcn_readlane(__float_as_int(B.y), k);
+            const float rx = x - p.x, ry = y - p.y, rz = z - p.z;
+            const float r2 = (rx * rx + ry * ry) + rz * rz;
+            const bool out = (DIRECT && r2 < 1e-10f) || (w2 < theta2 * r2);   // accepted (or skipped whole): the walk resumes behind its subtree
+            if (res < 0 && out) res = skip;
+        }
+    }
+    return res < 0 ? sp.first[seg] : res;
+}
+
+template <bool DIRECT, bool DBG = false>
+__global__ __launch_bounds__(64) void k_bh_walk_coop(const NodeDev* __restrict__ nodes, int n_nodes,
+                                                     const int* __restrict__ order, int n_order,
+                                                     const float4* __restrict__ own_pos, float4* __restrict__ acc,
+                                                     float g, float eps2, float theta2,
+                                                     unsigned long long* __restrict__ counters, WalkSplit split) {
+    const int lane = threadIdx.x;
+    const unsigned long long r_start = DBG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int seg = blockIdx.y;
+    if (split.diag_first) {   // heaviest (nearest) segments of a body group first, see k_bh_walk
+        const int K = gridDim.y;
+        const int diag = int((long long)blockIdx.x * K / gridDim.x);
+        const int kk = blockIdx.y;
+        const int off = (kk & 1) ? (kk + 1) / 2 : -(kk / 2);
+        seg = ((diag + off) % K + K) % K;
+    }
+    const int s1 = split.first[seg + 1];
+    const int t = blockIdx.x * 64 + lane;
+    const bool live = t < n_order;
+    const int b = live ? order[t] : 0;
+    const float4 p = live ? own_pos[b] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int resume = walk_entry_coop<DIRECT>(nodes, split, seg, p, theta2, lane);
+    if (!live) resume = 0x7fffffff;
+    int first = resume;
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+    int i = __builtin_amdgcn_readfirstlane(first);   // wave-uniform node index: the first node any lane visits
+    unsigned int n_acc = 0, n_vis = 0;               // wave totals (scalar)
+    unsigned long long r_mid = 0;
+    unsigned int n_it = 0, n_fill = 0;
+    if (DBG) r_mid = __builtin_amdgcn_s_memrealtime();
+    // the window: lane l holds record base + l in registers; the next kWin records are requested as soon as a window
+    // is in place (the index only moves forward) and are usually there when the index gets to them
+    int base = i;
+    float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa, pa = wa, pb = wa;
+    if (i < s1) {
+        const int idx = min(base + lane, n_nodes - 1);
+        wa = nodes[idx].a; wb = nodes[idx].b;
+        const int pidx = min(base + kWin + lane, n_nodes - 1);
+        pa = nodes[pidx].a; pb = nodes[pidx].b;
+        if (DBG) ++n_fill;
+    }
+    while (i < s1) {
+        if (DBG) ++n_it;
+        if (unsigned(i - base) >= unsigned(kWin)) {  // the index left the window
+            if (DBG) ++n_fill;
+            if (unsigned(i - base - kWin) < unsigned(kWin)) {   // ... into the records requested ahead
+                wa = pa; wb = pb;
+                base += kWin;
+            } else {                                            // ... beyond them: fetch from where it is now
+                base = i;
+                const int idx = min(base + lane, n_nodes - 1);
+                wa = nodes[idx].a; wb = nodes[idx].b;
+            }
+            const int pidx = min(base + kWin + lane, n_nodes - 1);
+            pa = nodes[pidx].a; pb = nodes[pidx].b;
+        }
+        const int r = i - base;
+        const float nx = lane_value(wa.x, r), ny = lane_value(wa.y, r), nz = lane_value(wa.z, r), nm = lane_value(wa.w, r);
+        const float w2 = lane_value(wb.x, r);
+        const int skip = __builtin_amdgcn_readlane(__float_as_int(wb.y), r);
+        const bool active = i >= resume;
+        const float rx = nx - p.x, ry = ny - p.y, rz = nz - p.z;           // :190
+        const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
+        bool accept, open;
+        if (DIRECT) {
+            const bool near = active && (r2 < 1e-10f);                      // llm :933-935: skipped whole
+            accept = active && !near && ((w2 < theta2 * r2) || skip == i + 1);  // llm :938 accepted cell, :958-972 leaf
+            open = active && !near && !accept;
+            if (near) resume = skip;
+        } else {
+            accept = active && (w2 < theta2 * r2);                          // :192
+            open = active && !accept;
+        }
+        if (accept) {
+            const float rinv = __builtin_amdgcn_rsqf(r2 + eps2);
+            const float k = (g * nm) * ((rinv * rinv) * rinv);
+            ax += rx * k; ay += ry * k; az += rz * k;
+            resume = skip;
+        }
+        n_vis += unsigned(__popcll(__builtin_amdgcn_ballot_w64(active)));
+        n_acc += unsigned(__popcll(__builtin_amdgcn_ballot_w64(accept)));
+        i = __builtin_amdgcn_ballot_w64(open) != 0ull ? i + 1 : skip;
+    }
+    if (live) (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+    if (DBG) {   // per wave: start, end (100 MHz ticks), iterations | window fills << 24 | entry replay ticks << 44
+        const unsigned w = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && w < 65536) {
+            nbody_bh_stamps[3 * w] = r_start; nbody_bh_stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+            nbody_bh_stamps[3 * w + 2] = (unsigned long long)n_it | ((unsigned long long)n_fill << 24) | ((unsigned long long)min(0xFFFFull, r_mid - r_start) << 44);
+        }
+    }
+    if (lane == 0 && counters) {
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
+    }
+}
+
+// ---- Variant 5: cooperative BLOCK walk over a level-order copy of the tree (kernels_tree.hip build_bfs_layout).
+// Variant 4 showed what a wave-cooperative walk is worth and what limits it: the union of 64 neighbours' walks is
+// only 1.7x one body's walk, but in the pre-order array consecutive visited nodes come in runs of ~1.5, so nearly every
+// iteration needs a record from a new place (a window of 64 records is refilled every 5.8 iterations and 91 % of what
+// it fetches is never looked at: 2.7 GB of L2 traffic per launch, 400-500 cycles per iteration).  What IS contiguous
+// is a node's list of children when the nodes are stored level by level.  So: a wave keeps a stack of
+// {child block, mask of the lanes that opened the parent}; it pops a block, fetches its <= 8 records with one load
+// (lanes 0..7), tests every child for the lanes of the mask, adds the accepted ones, and pushes the blocks of the
+// children some lane opened.  tools/bh_visit_hist.py, N = 65 536, theta = 0.5: 606 block fetches per wave instead of
+// 3 368 dependent record fetches, 5.55 children per block, at most 54 stack entries.
+// Every lane evaluates exactly the opening tests of its own walk (so the counters equal k_bh_walk's and the
+// oracle's); it adds the accepted monopoles of a block's children before those of their subtrees, in reverse
+// orthant order -- a fixed order, but not the pre-order of k_bh_walk: accelerations agree to rounding, not bit for bit.
+// The node-range split works on the records' pre-order indices: a subtree entirely outside [s0, s1) is not touched,
+// a node before s0 whose subtree reaches into the range is only tested (it belongs to an earlier segment).
+constexpr int kBlockStack = 160;   // entries; a walk holds <= 7 per level + 1, the device build stops at 21 levels
+
+template <bool DIRECT, bool DBG = false>
+__global__ __launch_bounds__(64) void k_bh_walk_block(const NodeDev* __restrict__ bfs, int n_nodes,
+                                                      const int* __restrict__ order, int n_order,
+                                                      const float4* __restrict__ own_pos, float4* __restrict__ acc,
+                                                      float g, float eps2, float theta2,
+                                                      unsigned long long* __restrict__ counters, WalkSplit split) {
+    __shared__ uint4 stack[kBlockStack];   // {block position, mask lo, mask hi, -}
+    const int lane = threadIdx.x;
+    const unsigned long long r_start = DBG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    int seg = blockIdx.y;
+    if (split.diag_first) {   // heaviest (nearest) segments of a body group first, see k_bh_walk
+        const int K = gridDim.y;
+        const int diag = int((long long)blockIdx.x * K / gridDim.x);
+        const int kk = blockIdx.y;
+        const int off = (kk & 1) ? (kk + 1) / 2 : -(kk / 2);
+        seg = ((diag + off) % K + K) % K;
+    }
+    const int s0 = split.first[seg], s1 = split.first[seg + 1];
+    const int t = blockIdx.x * 64 + lane;
+    const bool live = t < n_order;
+    const int b = live ? order[t] : 0;
+    const float4 p = live ? own_pos[b] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    unsigned int n_acc = 0, n_vis = 0, n_blk = 0, n_it = 0;
+    int sp = 0;
+    {
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(live);
+        if (lane == 0) stack[0] = make_uint4(0u, unsigned(m0), unsigned(m0 >> 32), 0u);   // the root: a block of one
+        sp = 1;
+    }
+    while (sp > 0) {
+        --sp;
+        __syncthreads();                                   // (one wave per workgroup: orders the LDS accesses)
+        const uint4 e = stack[sp];
+        const int base = __builtin_amdgcn_readfirstlane(int(e.x));
+        const unsigned long long M = ((unsigned long long)__builtin_amdgcn_readfirstlane(int(e.y)) & 0xFFFFFFFFull)
+                                   | ((unsigned long long)__builtin_amdgcn_readfirstlane(int(e.z)) << 32);
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 0.f, __int_as_float(int(0x80000000u)));
+        if (lane < 8) {
+            const int idx = min(base + lane, n_nodes - 1);
+            ra = bfs[idx].a; rb = bfs[idx].b;
+        }
+        // children in the block: up to and including the first record with the last-sibling flag
+        const unsigned long long lastm = __builtin_amdgcn_ballot_w64(lane < 8 && __float_as_int(rb.w) < 0);
+        const int nchild = __builtin_ctzll(lastm) + 1;
+        const bool active = (M >> lane) & 1ull;
+        if (DBG) ++n_blk;
+        for (int c = nchild - 1; c >= 0; --c) {            // reverse, so that the pushes pop in orthant order
+            const int pre = __builtin_amdgcn_readlane(__float_as_int(rb.y), c);
+            const int skp = __builtin_amdgcn_readlane(__float_as_int(rb.z), c);
+            if (skp <= s0 || pre >= s1) continue;          // the subtree lies outside this segment
+            const bool in_seg = pre >= s0;                 // else: an ancestor of the segment's first node, tested only
+            if (DBG) ++n_it;
+            const float nx = lane_value(ra.x, c), ny = lane_value(ra.y, c), nz = lane_value(ra.z, c), nm = lane_value(ra.w, c);
+            const float w2 = lane_value(rb.x, c);
+            const float rx = nx - p.x, ry = ny - p.y, rz = nz - p.z;       // :190
+            const float r2 = (rx * rx + ry * ry) + rz * rz;                 // :191
+            const bool leaf = skp == pre + 1;
+            bool accept, open;
+            if (DIRECT) {
+                const bool near = active && (r2 < 1e-10f);                  // llm :933-935: skipped whole
+                accept = active && !near && ((w2 < theta2 * r2) || leaf);   // llm :938 accepted cell, :958-972 leaf
+                open = active && !near && !accept;
+            } else {
+                accept = active && (w2 < theta2 * r2);                      // :192
+                open = active && !accept;
+            }
+            if (in_seg) {
+                if (accept) {
+                    const float rinv = __builtin_amdgcn_rsqf(r2 + eps2);
+                    const float k = (g * nm) * ((rinv * rinv) * rinv);
+                    ax += rx * k; ay += ry * k; az += rz * k;
+                }
+                n_vis += unsigned(__popcll(__builtin_amdgcn_ballot_w64(active)));
+                n_acc += unsigned(__popcll(__builtin_amdgcn_ballot_w64(accept)));
+            }
+            const unsigned long long mo = __builtin_amdgcn_ballot_w64(open);
+            if (mo != 0ull && !leaf && sp < kBlockStack) {
+                const int child = __builtin_amdgcn_readlane(__float_as_int(rb.w), c) & 0x7fffffff;
+                if (lane == 0) stack[sp] = make_uint4(unsigned(child), unsigned(mo), unsigned(mo >> 32), 0u);
+                ++sp;
+            }
+        }
+    }
+    if (live) (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+    if (DBG) {   // per wave: start, end (100 MHz ticks), children tested | blocks fetched << 24
+        const unsigned w = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && w < 65536) {
+            nbody_bh_stamps[3 * w] = r_start; nbody_bh_stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+            nbody_bh_stamps[3 * w + 2] = (unsigned long long)n_it | ((unsigned long long)n_blk << 24);
+        }
+    }
+    if (lane == 0 && counters) {
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
+    }
+}
+
 // ---- Variant 3: the most-visited node records staged in LDS (north_star's "cell list staged in LDS").
 // tools/bh_visit_hist.py: at N = 65 536, theta = 0.5 the walks evaluate 1.2e8 opening tests on 97 179 nodes, and
 // the ~2 500 nodes whose grandparent cell holds >= 1 024 bodies take 70 % of them.  tools/microbench_gather.hip:
@@ -530,7 +797,7 @@ extern "C" int nbody_bh_read_stamps(unsigned long long* out, int n_waves) {
 }
 extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group: 0 = automatic
 extern "C" int nbody_bh_walk_order = 1;    // 1: a group's segments are dispatched nearest-first (heaviest first), 0: in index order
-extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative, 2 = two lanes per body, 3 = hot records in LDS
+extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative (scalar loads), 2 = two lanes per body, 3 = hot records in LDS, 4 = wave-cooperative over a window of records, 5 = cooperative block walk (level-order copy)
 extern "C" int nbody_bh_walk_lds_block = 1024;  // variant 3: threads per workgroup (they share one LDS table)
 namespace nbody {
 
@@ -597,8 +864,20 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
         else { if (leaf_direct) WALK_LDS(true, 1024); else WALK_LDS(false, 1024); }
 #undef WALK_LDS
     } else {
+    if (fast_math && nbody_bh_walk_variant == 5 && t.bfs && t.n_nodes > 0) {
+        (void)build_bfs_layout(s, t.nodes, t.n_nodes, t.bfs_ws, t.bfs_cap, t.bfs);
+#define WALK_BLOCK(...) hipLaunchKernelGGL((k_bh_walk_block<__VA_ARGS__>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.bfs), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
+        if (nbody_bh_walk_debug && !leaf_direct) WALK_BLOCK(false, true);
+        else if (leaf_direct) WALK_BLOCK(true);
+        else WALK_BLOCK(false);
+#undef WALK_BLOCK
+    } else if (fast_math && nbody_bh_walk_variant == 4) {
+        if (nbody_bh_walk_debug && !leaf_direct) hipLaunchKernelGGL((k_bh_walk_coop<false, true>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
+        else if (leaf_direct) hipLaunchKernelGGL((k_bh_walk_coop<true>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
+        else hipLaunchKernelGGL((k_bh_walk_coop<false>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
+    } else {
     // the alternative walks are fast-math experiments with the reference leaf rule only
-    const int variant = (leaf_direct || !fast_math) ? 0 : (nbody_bh_walk_variant == 3 ? 0 : nbody_bh_walk_variant);
+    const int variant = (leaf_direct || !fast_math) ? 0 : (nbody_bh_walk_variant >= 3 ? 0 : nbody_bh_walk_variant);
     if (variant == 2) grid.x = (2 * t.n_order + kWalkBlock - 1) / kWalkBlock;
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
     if (variant == 1) WALK(k_bh_walk_wave, true);
@@ -616,6 +895,7 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     else if (nbody_bh_walk_debug && fast_math) WALK(k_bh_walk, true, false, true);
     else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
+    }
     }
     if (t.n_split > 1) {
         const dim3 rg((t.n_order + 255) / 256);

@@ -400,6 +400,80 @@ void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_
                        n_split, first, n_anc, anc, max_anc);
 }
 
+// ---- level-order copy of the tree for the cooperative block walk (kernels_bh.hip k_bh_walk_block): the nodes sorted
+// by depth, ties in pre-order, so that the children of a node are consecutive records (all descendants of a node at
+// one depth lie between its pre-order bounds).  Record: {com, mass | w^2, pre-order index, pre-order skip link,
+// position of the first child | last-sibling flag in bit 31}.  Works on any pre-order array (host or device build):
+// the depth comes from the width, which halves exactly per level (shared.rs:256-272).
+namespace {
+
+__global__ __launch_bounds__(256) void k_bfs_keys(const float4* __restrict__ nodes, int n_nodes, unsigned char* __restrict__ depth,
+                                                  unsigned int* __restrict__ keys, int* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    // w^2 = W^2 * 4^-d exactly: the exponent fields differ by 2d
+    const int d = (__float_as_int(nodes[1].x) - __float_as_int(nodes[2 * i + 1].x)) >> 24;
+    const int dc = min(max(d, 0), 63);
+    depth[i] = (unsigned char)dc;
+    keys[i] = (unsigned int)dc;
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_bfs_inverse(const int* __restrict__ perm, int n_nodes, int* __restrict__ pos) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n_nodes) pos[perm[p]] = p;
+}
+
+__global__ __launch_bounds__(256) void k_bfs_records(const float4* __restrict__ nodes, int n_nodes, const int* __restrict__ perm,
+                                                     const int* __restrict__ pos, const unsigned char* __restrict__ depth,
+                                                     float4* __restrict__ out) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_nodes) return;
+    const int i = perm[p];
+    const float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+    const int skip = __float_as_int(b.y);
+    const int child = (skip > i + 1) ? pos[i + 1] : 0;                        // the first child is the next node in pre-order
+    const bool last = (skip >= n_nodes) || (depth[skip] < depth[i]);          // behind the subtree: a sibling, or an ancestor's sibling
+    out[2 * p] = a;
+    out[2 * p + 1] = make_float4(b.x, __int_as_float(i), __int_as_float(skip), __int_as_float(child | (last ? int(0x80000000u) : 0)));
+}
+
+size_t bfs_sort_bytes(size_t n_cap) {
+    size_t b = 0;
+    unsigned int* k = nullptr; int* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, b, k, k, v, v, n_cap, 0, 6, 0);
+    return (b + 255) / 256 * 256;
+}
+
+}  // namespace
+
+size_t bfs_workspace_bytes(size_t n_cap) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    return bfs_sort_bytes(n_cap) + 2 * al(n_cap * 4) + 2 * al(n_cap * 4) + al(n_cap * 4) + al(n_cap) + 256;
+}
+
+// enqueues the level-order copy of `nodes` (pre-order, n_nodes records) into `out`; 0 on success
+int build_bfs_layout(hipStream_t s, const float4* nodes, int n_nodes, void* workspace, size_t n_cap, float4* out) {
+    if (n_nodes <= 0) return 0;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    char* p = static_cast<char*>(workspace);
+    const size_t sort_bytes = bfs_sort_bytes(n_cap);
+    void* tmp = p; p += sort_bytes;
+    auto* keys_in = reinterpret_cast<unsigned int*>(p); p += al(n_cap * 4);
+    auto* keys = reinterpret_cast<unsigned int*>(p); p += al(n_cap * 4);
+    auto* vals_in = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    auto* perm = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    auto* pos = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    auto* depth = reinterpret_cast<unsigned char*>(p);
+    const dim3 grid((n_nodes + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_bfs_keys, grid, block, 0, s, nodes, n_nodes, depth, keys_in, vals_in);
+    size_t tb = sort_bytes;
+    if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys, vals_in, perm, size_t(n_nodes), 0, 6, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_bfs_inverse, grid, block, 0, s, perm, n_nodes, pos);
+    hipLaunchKernelGGL(k_bfs_records, grid, block, 0, s, nodes, n_nodes, perm, pos, depth, out);
+    return 0;
+}
+
 // bytes at the start of the build workspace that rocPRIM uses as scratch (free between builds)
 size_t tree_build_tmp_bytes(size_t n_cap) { return scratch_bytes(n_cap); }
 

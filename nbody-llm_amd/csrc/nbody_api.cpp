@@ -83,6 +83,9 @@ struct NbodyHandle {
     float4* d_walk = nullptr;    // [walk_cap + 1] records with explicit links
     int* d_unified = nullptr;    // [walk_cap + 1]
     size_t walk_cap = 0;         // nodes
+    float4* d_bfs = nullptr;     // cooperative block walk (variant 5): level-order copy of the nodes
+    void* d_bfs_ws = nullptr;
+    size_t bfs_cap = 0;          // nodes
     float4* d_hot = nullptr;     // [hot_cap] records
     int hot_cap = 0;
     int* d_hot_info = nullptr;   // [2] slot counter, nodes flagged by the last pass
@@ -453,6 +456,19 @@ int ensure_nested_stack(NbodyHandle* h, nbody::TreeDev* td) {
 // fast math, variant 3: buffers of the LDS-staged walk and the threshold that picks the staged nodes.
 // Called after this step's first host synchronisation, so h_hot_info holds the previous pass's flagged count.
 int setup_lds_walk(NbodyHandle* h, nbody::TreeDev* td, size_t n_tree) {
+    // (its per-wave stack holds the 21 levels of the device build; a deeper host-built tree is walked by k_bh_walk)
+    if (h->cfg.math_mode == NBODY_MATH_FAST && nbody_bh_walk_variant == 5 && (h->tree_on_device || h->tree.max_depth <= 21)) {
+        if (h->bfs_cap < h->d_node_cap) {
+            if (h->d_bfs) (void)hipFree(h->d_bfs);
+            if (h->d_bfs_ws) (void)hipFree(h->d_bfs_ws);
+            h->d_bfs = nullptr; h->d_bfs_ws = nullptr; h->bfs_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_bfs, h->d_node_cap * 2 * sizeof(float4)));
+            HIP_TRY(h, hipMalloc(&h->d_bfs_ws, nbody::bfs_workspace_bytes(h->d_node_cap)));
+            h->bfs_cap = h->d_node_cap;
+        }
+        td->bfs = h->d_bfs; td->bfs_ws = h->d_bfs_ws; td->bfs_cap = h->bfs_cap;
+        return NBODY_OK;
+    }
     if (h->cfg.math_mode != NBODY_MATH_FAST || nbody_bh_walk_variant != 3 || nbody_bh_hot_cap <= 0) return NBODY_OK;
     const int M = std::min(nbody_bh_hot_cap, 5000);  // 160 KB of LDS per CU, 32 B per record
     if (h->walk_cap < h->d_node_cap) {
@@ -866,7 +882,7 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
-                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_walk, h->d_unified, h->d_hot, h->d_hot_info, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
+                   h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_walk, h->d_unified, h->d_hot, h->d_hot_info, h->d_bfs, h->d_bfs_ws, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info, h->h_hot_info};
     for (void* p : host) if (p) (void)hipHostFree(p);

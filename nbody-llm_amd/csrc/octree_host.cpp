@@ -234,6 +234,7 @@ struct Emit {
     std::vector<NodeRec> nodes;
     std::vector<int32_t> order;
     bool too_deep = false;
+    int max_depth = 0;
 };
 
 // classify + fold; returns per-orthant counts in cnt[8], the node's mass and com
@@ -267,6 +268,7 @@ inline void scatter(const Item* src, Item* dst, const uint8_t* code, int n, cons
 // pn, gpn: bodies in the parent and grandparent cells (NodeB::hot)
 void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int depth, Emit& e, int pn, int gpn) {
     const int me = int(e.nodes.size());
+    if (depth > e.max_depth) e.max_depth = depth;
     e.nodes.push_back(NodeRec{NodeA{0.f, 0.f, 0.f, 0.f}, NodeB{box.w * box.w, me + 1, gpn, -1}});
     if (n == 0) return;
     if (n == 1) {
@@ -504,7 +506,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
     pool.run(int(tasks.size()), [&](int i) {
         Task& tk = tasks[by_size[i]];
         Emit& e = *tk.out;
-        e.nodes.clear(); e.order.clear(); e.too_deep = false;
+        e.nodes.clear(); e.order.clear(); e.too_deep = false; e.max_depth = tk.depth;
         build_rec(tk.src, tk.tmp, tk.code, tk.n, tk.box, tk.depth, e, tk.pn, tk.gpn);
     });
 
@@ -542,7 +544,18 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         }
         if (!em.order.empty()) std::memcpy(&out.order[ofirst[e]], em.order.data(), em.order.size() * sizeof(int32_t));
     });
-    for (auto& tk : tasks) out.too_deep = out.too_deep || tk.out->too_deep;
+    out.max_depth = 0;
+    for (auto& tk : tasks) { out.too_deep = out.too_deep || tk.out->too_deep; out.max_depth = std::max(out.max_depth, tk.out->max_depth); }
+    {   // nodes above the subtree tasks: depth from the width, which halves exactly per level
+        int32_t b0, bi;
+        const float w2_root = root.w * root.w;
+        std::memcpy(&b0, &w2_root, 4);
+        for (const TopEntry& te : top) {
+            if (te.task >= 0) continue;
+            std::memcpy(&bi, &te.b.w2, 4);
+            out.max_depth = std::max(out.max_depth, int((b0 - bi) >> 24));
+        }
+    }
     lap("splice");
 }
 

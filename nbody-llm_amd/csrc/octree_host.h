@@ -62,6 +62,7 @@ struct HostTree {
     size_t n_nodes = 0, n_order = 0;
     size_t cap_nodes = 0, cap_order = 0;
     bool too_deep = false;
+    int max_depth = 0;         // depth of the deepest node (root = 0)
     void* (*alloc)(size_t) = nullptr;  // null -> malloc/free
     void (*release)(void*) = nullptr;
     void reserve(size_t n_nodes_wanted, size_t order_n);

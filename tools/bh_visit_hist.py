@@ -106,3 +106,36 @@ for K in (1, 8):
                            C.byref(a), C.byref(d), C.byref(r), C.byref(mx))
             ng = (n + 63) // 64
             print(f"  K={K} W={W:3d} min-resume={um}: iterations {a.value / ng:7.0f}  dead {d.value / ng:6.0f}  window loads {r.value / ng:6.0f}  longest wave {mx.value}")
+
+hl.coop_items.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int,
+                          C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
+print("cooperative walk, items = fine segments within R of the group's own place + doubling runs beyond: Kf, R: items/group, iterations/group, longest item, items by iterations (bins of 64)")
+for Kf, R, cap in ((384, 8, 1 << 30), (384, 8, 32), (384, 8, 16), (384, 8, 8), (768, 16, 16), (768, 16, 8), (192, 4, 4), (192, 4, 8)):
+    hl.set_run_cap(cap)
+    a, it, mx = C.c_int64(), C.c_int64(), C.c_int64()
+    hist = np.zeros(64, np.int32)
+    hl.coop_items(com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, pos4.ctypes.data, order_arr.ctypes.data, n, theta * theta, Kf, R,
+                  C.byref(a), C.byref(it), C.byref(mx), hist.ctypes.data)
+    ng = (n + 63) // 64
+    nz = np.nonzero(hist)[0].max() + 1
+    print(f"  Kf={Kf:4d} R={R:2d} cap={min(cap, 9999):4d}: items/group {a.value / ng:5.1f}  iterations/group {it.value / ng:6.0f}  longest {mx.value:5d}  hist {hist[:nz].tolist()}")
+
+hl.coop_window_policy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+print("cooperative walk window policy (per group of 64 bodies): wmin wmax grow shrink: iterations, fills, records fetched, KiB, records per visited node")
+for wmin, wmax, gd, sd in ((64, 64, 1, 1), (32, 32, 1, 1), (16, 16, 1, 1), (8, 8, 1, 1), (4, 4, 1, 1), (2, 2, 1, 1), (1, 1, 1, 1),
+                           (4, 64, 2, 4), (4, 64, 2, 8), (8, 64, 2, 4), (8, 64, 4, 8), (4, 32, 2, 4), (2, 64, 2, 4)):
+    a, f, r = C.c_int64(), C.c_int64(), C.c_int64()
+    hl.coop_window_policy(com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, pos4.ctypes.data, order_arr.ctypes.data, n, theta * theta,
+                          wmin, wmax, gd, sd, C.byref(a), C.byref(f), C.byref(r))
+    ng = (n + 63) // 64
+    print(f"  {wmin:3d} {wmax:3d} {gd} {sd}: iterations {a.value / ng:6.0f}  fills {f.value / ng:6.0f}  records {r.value / ng:7.0f}  {r.value / ng * 32 / 1024:7.1f} KiB  {r.value / a.value:5.2f} per visit")
+
+hl.block_walk_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+bl, ch, ms, lt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+hl.block_walk_counts(com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, pos4.ctypes.data, order_arr.ctypes.data, n, theta * theta,
+                     C.byref(bl), C.byref(ch), C.byref(ms), C.byref(lt))
+ng = (n + 63) // 64
+print(f"block walk (children stored contiguously), per group of 64 bodies: blocks fetched {bl.value / ng:.0f}, children tested {ch.value / ng:.0f} "
+      f"({ch.value / bl.value:.2f} per block), lane tests {lt.value / n:.0f} per body, deepest stack {ms.value} entries")
