@@ -17,6 +17,14 @@ struct Shard {
     int* seg_count = nullptr;    // [n_seg] bodies alive per segment
     int* escaped = nullptr;      // [1] bodies of the own segment flagged out of bounds by drift
     unsigned char* keep = nullptr;  // [seg_cap] 1 = in bounds
+    // K4 (parallel retain): per-tile status words of the decoupled look-back {epoch | flag | count} and the epoch
+    unsigned long long* tile_state = nullptr;   // [ceil(seg_cap / 1024)]
+    int* epoch = nullptr;                       // [1]
+    // Barnes-Hut steps enqueued without a host round trip (device tree): [0] != 0 = "poisoned" (a build needed the
+    // host: deeper than the device build's 21 levels, or more nodes than allocated) -- every kernel that changes the
+    // state then does nothing until the host has dealt with it; [1] = steps completed since the host last looked
+    int* poison = nullptr;
+    unsigned long long* inter = nullptr;        // [1] brute force: directed interactions evaluated, n_own * (n_total - 1) per force pass from the LIVE counts
     int n_seg = 1;
     int seg_cap = 0;
     int my_seg = 0;
@@ -36,7 +44,7 @@ void launch_soa_to_aos(hipStream_t s, float* aos, int stride_f, int n, const flo
 // K1: integrate_pre_force (shared.rs:135-140) + Bounds::contains flags (shared.rs:210-212)
 void launch_drift_half(hipStream_t s, const Shard& sh, int n_upper, float dt, BoundsF b);
 // K4: Vec::retain (brute_force.rs:86): in-place order-preserving compaction, no-op unless *escaped
-void launch_compact(hipStream_t s, const Shard& sh);
+void launch_compact(hipStream_t s, const Shard& sh, int n_upper);
 // K3: integrate_after_force (shared.rs:141-148)
 void launch_kick_drift(hipStream_t s, const Shard& sh, int n_upper, float dt);
 
@@ -113,6 +121,10 @@ struct TreeDev {
     int* hot_info = nullptr;         // [0] slot counter of the pass under way, [1] nodes the last pass flagged
     int hot_cap = 0;                 // LDS table entries
     int hot_threshold = 0;           // a node is staged if NodeB::hot >= this
+    // unsynchronised steps (device tree, no read-back): kernels stop when *poison != 0 and take the number of bodies
+    // to walk from the device
+    const int* poison = nullptr;
+    const int* n_order_dev = nullptr;
     // fast math: the cooperative block walk (k_bh_walk_block) reads this level-order copy of `nodes`, built per step
     float4* bfs = nullptr;           // [n_nodes] records {com, mass | w^2, pre-order index, pre-order skip, first child | last flag}
     void* bfs_ws = nullptr;          // workspace of build_bfs_layout
@@ -139,12 +151,13 @@ void launch_tree_cat(hipStream_t s, const Shard& sh, const TreeCat& c);
 int launch_tree_own_order(hipStream_t s, const int* order, const TreeCat& c, int n_total_upper, void* tmp, size_t tmp_bytes);
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
-                        int* out_info, TreeDevWork* work);
+                        int* out_info, TreeDevWork* work, int want_hot = 0 /* fill NodeB::hot (LDS-staged walk only) */);
 // level-order copy of a pre-order node array for the cooperative block walk
 size_t bfs_workspace_bytes(size_t n_cap);
 int build_bfs_layout(hipStream_t s, const float4* nodes, int n_nodes, void* workspace, size_t n_cap, float4* out);
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
-                           int* n_anc, int* anc, int max_anc);
+                           int* n_anc, int* anc, int max_anc, const int* info = nullptr /* device: {n_nodes, flags, n}: overrides n, n_nodes */,
+                           int* poison = nullptr /* made sticky when the build raised a flag */);
 
 // the walk's {accepted, visited} counters: this many u64 pairs, to be summed by the reader
 #define NBODY_WALK_COUNTER_SLOTS 1024u

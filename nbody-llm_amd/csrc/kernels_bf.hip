@@ -20,17 +20,26 @@
 
 namespace nbody {
 
+// NbodyStats::interactions of a brute-force pass: n_own * (n_total - 1) from the live counts (one thread per launch)
+__device__ __forceinline__ void count_interactions(unsigned long long* inter, const int* seg_count, int n_seg, int n_own) {
+    long long tot = 0;
+    for (int s = 0; s < n_seg; ++s) tot += seg_count[s];
+    if (tot > 0) atomicAdd(inter, (unsigned long long)n_own * (unsigned long long)(tot - 1));
+}
+
 // ------------------------------------------------------------------------------------ strict
 constexpr int kStrictBlock = 256;
 constexpr int kStrictTile = 1024;
 
 __global__ __launch_bounds__(kStrictBlock) void k_bf_strict(const float4* __restrict__ pos_all,
                                                             const int* __restrict__ seg_count, int n_seg, int seg_cap,
-                                                            int my_seg, float4* __restrict__ acc, float g, float eps2) {
+                                                            int my_seg, float4* __restrict__ acc, float g, float eps2,
+                                                            unsigned long long* __restrict__ inter) {
     __shared__ float4 tile[kStrictTile];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kStrictBlock + tid;
     const int n_own = seg_count[my_seg];
+    if (inter && blockIdx.x == 0 && tid == 0) count_interactions(inter, seg_count, n_seg, n_own);
     const float4 pi = (i < n_own) ? pos_all[size_t(my_seg) * seg_cap + i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float ax = 0.f, ay = 0.f, az = 0.f;  // brute_force.rs:65-67
     for (int s = 0; s < n_seg; ++s) {
@@ -64,7 +73,8 @@ __global__ __launch_bounds__(kStrictBlock) void k_bf_strict(const float4* __rest
 template <int IPT, int WAVES, int TILE>
 __global__ __launch_bounds__(WAVES * 64) void k_bf_fast(const float4* __restrict__ pos_all,
                                                         const int* __restrict__ seg_count, int n_seg, int seg_cap,
-                                                        int my_seg, float4* __restrict__ acc, float g, float eps2) {
+                                                        int my_seg, float4* __restrict__ acc, float g, float eps2,
+                                                        unsigned long long* __restrict__ inter) {
     constexpr int NT = WAVES * 64;
     constexpr int SLICE = TILE / WAVES;
     static_assert(TILE % WAVES == 0, "tile must split evenly over the waves");
@@ -75,6 +85,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_bf_fast(const float4* __restrict
     const int ibase = blockIdx.x * (64 * IPT);
     const int n_own = seg_count[my_seg];
     const float4* __restrict__ own = pos_all + size_t(my_seg) * seg_cap;
+    if (inter && blockIdx.x == 0 && tid == 0) count_interactions(inter, seg_count, n_seg, n_own);
 
     float px[IPT], py[IPT], pz[IPT], ax[IPT], ay[IPT], az[IPT];
 #pragma unroll
@@ -158,14 +169,14 @@ void launch_bf_forces_strict(hipStream_t s, const Shard& sh, int n_upper, float 
     if (n_upper <= 0) return;
     int blocks = (n_upper + kStrictBlock - 1) / kStrictBlock;
     hipLaunchKernelGGL(k_bf_strict, dim3(blocks), dim3(kStrictBlock), 0, s, sh.pos_all, sh.seg_count, sh.n_seg,
-                       sh.seg_cap, sh.my_seg, sh.acc, g, g_soft2);
+                       sh.seg_cap, sh.my_seg, sh.acc, g, g_soft2, sh.inter);
 }
 
 template <int IPT, int WAVES, int TILE>
 static void launch_fast_cfg(hipStream_t s, const Shard& sh, int n_upper, float g, float eps2) {
     int blocks = (n_upper + 64 * IPT - 1) / (64 * IPT);
     hipLaunchKernelGGL((k_bf_fast<IPT, WAVES, TILE>), dim3(blocks), dim3(WAVES * 64), 0, s, sh.pos_all,
-                       sh.seg_count, sh.n_seg, sh.seg_cap, sh.my_seg, sh.acc, g, eps2);
+                       sh.seg_count, sh.n_seg, sh.seg_cap, sh.my_seg, sh.acc, g, eps2, sh.inter);
 }
 
 }  // namespace nbody

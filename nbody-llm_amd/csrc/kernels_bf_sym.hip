@@ -361,8 +361,14 @@ template <bool KICK>
 __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict__ planes, int n_planes,
                                                        size_t plane_stride, const int* __restrict__ count, float g,
                                                        float4* __restrict__ acc, float4* __restrict__ pos,
-                                                       float4* __restrict__ vel, float dt) {
+                                                       float4* __restrict__ vel, float dt, const int* __restrict__ seg_count,
+                                                       int n_seg, unsigned long long* __restrict__ inter) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (inter && i == 0) {   // NbodyStats::interactions of this force pass, from the live counts
+        long long tot = 0;
+        for (int s = 0; s < n_seg; ++s) tot += seg_count[s];
+        if (tot > 0) atomicAdd(inter, (unsigned long long)(*count) * (unsigned long long)(tot - 1));
+    }
     if (i >= *count) return;
     // compensated (Kahan) sum over the planes, fixed order: the kernel is bandwidth-bound, the extra
     // flops are free, and with ~1000 planes at N = 2^20 a plain f32 sum would dominate the error
@@ -503,10 +509,10 @@ void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4
     const dim3 grid((n_upper + 255) / 256);
     if (kick_dt)
         hipLaunchKernelGGL(k_bf_sym_reduce<true>, grid, dim3(256), 0, s, planes, p.n_planes, p.plane_stride, sh.own_count(), g,
-                           sh.acc, sh.own_pos(), sh.vel, *kick_dt);
+                           sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.seg_count, sh.n_seg, sh.inter);
     else
         hipLaunchKernelGGL(k_bf_sym_reduce<false>, grid, dim3(256), 0, s, planes, p.n_planes, p.plane_stride, sh.own_count(), g,
-                           sh.acc, sh.own_pos(), sh.vel, 0.f);
+                           sh.acc, sh.own_pos(), sh.vel, 0.f, sh.seg_count, sh.n_seg, sh.inter);
 }
 
 }  // namespace nbody

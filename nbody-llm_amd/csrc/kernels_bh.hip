@@ -43,6 +43,8 @@ struct WalkSplit {
     float4* planes;          // [n_seg][plane_stride] partial accelerations (n_seg > 1)
     size_t plane_stride;
     int diag_first;          // k_bh_walk: segments of a body group in order of distance from its own place in the tree
+    const int* poison;       // unsynchronised steps: != 0 -> do nothing (Shard::poison); may be null
+    const int* n_order_dev;  // unsynchronised steps: the live number of bodies to walk (the host's is an upper bound); may be null
 };
 constexpr int kMaxAnc = 192;
 
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
         const int off = (kk & 1) ? (kk + 1) / 2 : -(kk / 2);
         seg = ((diag + off) % K + K) % K;
     }
+    if (split.poison && *split.poison) return;
+    if (split.n_order_dev) n_order = min(n_order, *split.n_order_dev);
     const int s1 = split.first[seg + 1];
     unsigned int n_acc = 0, n_vis = 0;
     unsigned long long r_beg = 0;
@@ -339,9 +343,12 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_nested(const NodeDev* __
                                                                const float4* __restrict__ own_pos,
                                                                float4* __restrict__ acc, float g, float eps2,
                                                                float theta2, unsigned long long* __restrict__ counters,
-                                                               float4* __restrict__ stack, size_t stack_stride) {
+                                                               float4* __restrict__ stack, size_t stack_stride,
+                                                               const int* __restrict__ poison, const int* __restrict__ n_order_dev) {
     const int t = blockIdx.x * kWalkBlock + threadIdx.x;
     unsigned int n_acc = 0, n_vis = 0;
+    if (poison && *poison) return;
+    if (n_order_dev) n_order = min(n_order, *n_order_dev);
     if (t < n_order) {
         const int b = order[t];
         const float4 p = own_pos[b];
@@ -806,8 +813,12 @@ template <bool KICK>
 __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ planes, int n_seg, size_t plane_stride,
                                                    const int* __restrict__ order, int n_order,
                                                    float4* __restrict__ acc, float4* __restrict__ pos,
-                                                   float4* __restrict__ vel, float dt) {
+                                                   float4* __restrict__ vel, float dt, int* __restrict__ poison,
+                                                   const int* __restrict__ n_order_dev) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (poison && *poison) return;
+    if (KICK && poison && t == 0) atomicAdd(poison + 1, 1);   // a step of an unsynchronised run is complete
+    if (n_order_dev) n_order = min(n_order, *n_order_dev);
     if (t >= n_order) return;
     const int b = order[t];
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -836,13 +847,14 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     if (t.nested_stack && !fast_math && !leaf_direct) {  // strict math: always the parity kernel
         hipLaunchKernelGGL(k_bh_walk_nested, dim3((t.n_order + kWalkBlock - 1) / kWalkBlock), dim3(kWalkBlock), 0, s,
                            reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g,
-                           g_soft2, theta2, counters, t.nested_stack, t.nested_stride);
+                           g_soft2, theta2, counters, t.nested_stack, t.nested_stride, t.poison, t.n_order_dev);
         return;
     }
     WalkSplit sp;
     sp.n_seg = t.n_split; sp.first = t.split_first; sp.anc = t.split_anc; sp.n_anc = t.split_n_anc;
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
     sp.diag_first = nbody_bh_walk_order;
+    sp.poison = t.poison; sp.n_order_dev = t.n_order_dev;
     dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
     if (fast_math && nbody_bh_walk_variant == 3 && t.hot_cap > 0 && t.walk) {
         const int M = t.hot_cap;
@@ -901,11 +913,11 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
         const dim3 rg((t.n_order + 255) / 256);
         if (kick_dt) {
             hipLaunchKernelGGL(k_bh_reduce<true>, rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order,
-                               t.n_order, sh.acc, sh.own_pos(), sh.vel, *kick_dt);
+                               t.n_order, sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.poison, t.n_order_dev);
             if (kicked) *kicked = 1;
         } else {
             hipLaunchKernelGGL(k_bh_reduce<false>, rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order,
-                               t.n_order, sh.acc, sh.own_pos(), sh.vel, 0.f);
+                               t.n_order, sh.acc, sh.own_pos(), sh.vel, 0.f, sh.poison, t.n_order_dev);
         }
     }
 }

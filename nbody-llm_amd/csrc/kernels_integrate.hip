@@ -3,13 +3,15 @@
 // K0  AoS <-> SoA transposition of PointParticle<f32,3> records (shared.rs:151-158)
 // K1  drift_half    = LeapFrogIntegrator::integrate_pre_force (shared.rs:135-140)
 //                     + the Bounds::contains test (shared.rs:210-212) that retain() applies next
-// K4  compact       = Vec::retain (brute_force.rs:86, barnes_hut.rs:267), order preserving
+// K4  compact       = Vec::retain (brute_force.rs:86, barnes_hut.rs:267), order preserving, one pass over many workgroups
 // K3  kick_drift    = LeapFrogIntegrator::integrate_after_force (shared.rs:141-148)
 //
 // All are pure streaming kernels, 16 B per lane per access (1 KiB per wave instruction).
 // Compiled with -ffp-contract=off: (v*0.5)*dt and a*dt are rounded products, then added, exactly
 // as the reference's nalgebra expressions evaluate.
 #include "kernels.h"
+
+#include <algorithm>
 
 namespace nbody {
 
@@ -39,7 +41,9 @@ __global__ __launch_bounds__(256) void k_soa_to_aos(float* __restrict__ aos, int
 
 __global__ __launch_bounds__(256) void k_drift_half(float4* __restrict__ pos, const float4* __restrict__ vel,
                                                     const int* __restrict__ count, unsigned char* __restrict__ keep,
-                                                    int* __restrict__ escaped, float dt, BoundsF b) {
+                                                    int* __restrict__ escaped, float dt, BoundsF b,
+                                                    const int* __restrict__ poison) {
+    if (poison && *poison) return;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= *count) return;
     float4 p = pos[k];
@@ -57,8 +61,10 @@ __global__ __launch_bounds__(256) void k_drift_half(float4* __restrict__ pos, co
 
 __global__ __launch_bounds__(256) void k_kick_drift(float4* __restrict__ pos, float4* __restrict__ vel,
                                                     const float4* __restrict__ acc, const int* __restrict__ count,
-                                                    float dt) {
+                                                    float dt, int* __restrict__ poison) {
+    if (poison && *poison) return;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && poison) atomicAdd(poison + 1, 1);   // a step of an unsynchronised Barnes-Hut run is complete
     if (k >= *count) return;
     float4 p = pos[k], v = vel[k], a = acc[k];
     v.x += a.x * dt;
@@ -71,49 +77,82 @@ __global__ __launch_bounds__(256) void k_kick_drift(float4* __restrict__ pos, fl
     pos[k] = p;
 }
 
-// One 1024-thread workgroup walks the segment in ascending chunks.  Within a chunk every thread
-// reads its record, the workgroup scans the keep flags (wave ballots + 16 wave totals in LDS),
-// and only after a barrier are the survivors written at base + rank.  Destination indices never
-// exceed source indices and later chunks are read after earlier chunks are written, so the
-// compaction is safe in place and preserves order like Vec::retain.  Launched every step, it
-// returns at once unless drift_half flagged an escape.
-__global__ __launch_bounds__(1024) void k_compact(float4* __restrict__ pos, float4* __restrict__ vel,
-                                                  float4* __restrict__ acc, const unsigned char* __restrict__ keep,
-                                                  int* __restrict__ count, int* __restrict__ escaped) {
+// K4: Vec::retain (brute_force.rs:86, barnes_hut.rs:267) -- order-preserving compaction of the own segment, in
+// place, in ONE pass over many workgroups (round 1 walked the segment with a single 1 024-thread workgroup: an escape
+// at N = 2^22 serialised 4 096 chunk iterations on one CU, ms-scale).  Launched every step, every workgroup returns at
+// once unless drift_half flagged an escape.
+//   * a tile = 1 024 consecutive bodies, one per thread; the thread loads its record, the workgroup counts and ranks
+//     its survivors (wave ballots + 16 wave totals in LDS);
+//   * tiles learn how many survivors precede them by decoupled look-back: a tile publishes {its own count}, then adds
+//     up its predecessors' published counts backwards until it meets one that already knows its inclusive prefix, and
+//     publishes its own inclusive prefix.  Status words carry the launch's epoch, so they never need resetting;
+//   * in place: a survivor moves to an index <= its own, i.e. into the source range of its own or an EARLIER tile.  A
+//     tile publishes only after its own records are in registers, and a tile's prefix is built from published words
+//     only, so -- by induction over the tiles it looked back over -- every earlier tile has finished reading before
+//     this tile knows where to write; inside a tile a barrier separates the loads from the stores.
+constexpr int kCompactTile = 1024;
+constexpr unsigned long long kTileAgg = 1ull, kTilePrefix = 2ull;
+__device__ __forceinline__ unsigned long long tile_word(int epoch, unsigned long long flag, int value) {
+    return ((unsigned long long)(unsigned)epoch << 34) | (flag << 32) | (unsigned long long)(unsigned)value;
+}
+
+__global__ __launch_bounds__(kCompactTile) void k_compact(float4* __restrict__ pos, float4* __restrict__ vel,
+                                                          float4* __restrict__ acc, const unsigned char* __restrict__ keep,
+                                                          int* __restrict__ count, int* __restrict__ escaped,
+                                                          unsigned long long* __restrict__ tile_state, int* __restrict__ epoch_p,
+                                                          const int* __restrict__ poison) {
+    if (poison && *poison) return;
     if (*escaped == 0) return;
     __shared__ int wave_total[16];
-    __shared__ int base_s;
+    __shared__ int excl_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
     const int n = *count;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (int c = 0; c < n; c += 1024) {
-        int k = c + tid;
-        bool kp = (k < n) && keep[k];
-        float4 p, v, a;
-        if (kp) { p = pos[k]; v = vel[k]; a = acc[k]; }
-        unsigned long long m = __ballot(kp);
-        int in_wave = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_total[wave] = __popcll(m);
-        __syncthreads();  // all reads of this chunk are done; wave totals visible
-        int before = 0, total = 0;
-        for (int w = 0; w < 16; ++w) {
-            int t = wave_total[w];
-            if (w < wave) before += t;
-            total += t;
-        }
-        int base = base_s;
-        if (kp) {
-            int d = base + before + in_wave;
-            pos[d] = p; vel[d] = v; acc[d] = a;
-        }
-        __syncthreads();  // everyone has read base_s / wave_total
-        if (tid == 0) base_s = base + total;
-        __syncthreads();
+    const int epoch = *epoch_p & 0x3fffffff;
+    const int k = tile * kCompactTile + tid;
+    const bool kp = (k < n) && keep[k];
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p, a = p;
+    if (kp) { p = pos[k]; v = vel[k]; a = acc[k]; }
+    const unsigned long long m = __ballot(kp);
+    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_total[wave] = __popcll(m);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's records are in registers ...
+    __syncthreads();                                   // ... and so are the whole tile's
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int t = wave_total[w];
+        if (w < wave) before += t;
+        total += t;
     }
     if (tid == 0) {
-        *count = base_s;
-        *escaped = 0;
+        volatile unsigned long long* st = tile_state;
+        int excl = 0;
+        if (tile == 0) {
+            st[0] = tile_word(epoch, kTilePrefix, total);
+        } else {
+            st[tile] = tile_word(epoch, kTileAgg, total);
+            __threadfence();
+            for (int j = tile - 1; j >= 0;) {
+                const unsigned long long wd = st[j];
+                if (int(wd >> 34) != epoch) continue;            // not published in this launch yet: look again
+                excl += int(unsigned(wd & 0xFFFFFFFFull));
+                if (((wd >> 32) & 3ull) == kTilePrefix) break;   // everything before j is in this word
+                --j;
+            }
+            st[tile] = tile_word(epoch, kTilePrefix, excl + total);
+        }
+        __threadfence();
+        excl_s = excl;
+        if (tile == int(gridDim.x) - 1) {   // the last tile's inclusive prefix is the new body count
+            *count = excl + total;
+            *escaped = 0;
+            *epoch_p = (epoch + 1) & 0x3fffffff;
+        }
+    }
+    __syncthreads();
+    if (kp) {
+        const int d = excl_s + before + in_wave;
+        pos[d] = p; vel[d] = v; acc[d] = a;
     }
 }
 
@@ -130,16 +169,17 @@ void launch_soa_to_aos(hipStream_t s, float* aos, int stride_f, int n, const flo
 void launch_drift_half(hipStream_t s, const Shard& sh, int n_upper, float dt, BoundsF b) {
     if (n_upper <= 0) return;
     hipLaunchKernelGGL(k_drift_half, dim3(blocks_for(n_upper, 256)), dim3(256), 0, s, sh.own_pos(), sh.vel,
-                       sh.own_count(), sh.keep, sh.escaped, dt, b);
+                       sh.own_count(), sh.keep, sh.escaped, dt, b, sh.poison);
 }
-void launch_compact(hipStream_t s, const Shard& sh) {
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.keep, sh.own_count(),
-                       sh.escaped);
+void launch_compact(hipStream_t s, const Shard& sh, int n_upper) {
+    if (n_upper <= 0) return;
+    hipLaunchKernelGGL(k_compact, dim3(blocks_for(n_upper, kCompactTile)), dim3(kCompactTile), 0, s, sh.own_pos(), sh.vel, sh.acc,
+                       sh.keep, sh.own_count(), sh.escaped, sh.tile_state, sh.epoch, sh.poison);
 }
 void launch_kick_drift(hipStream_t s, const Shard& sh, int n_upper, float dt) {
-    if (n_upper <= 0) return;
-    hipLaunchKernelGGL(k_kick_drift, dim3(blocks_for(n_upper, 256)), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc,
-                       sh.own_count(), dt);
+    // (launched even for an empty shard: the step counter of an unsynchronised run rides in it)
+    hipLaunchKernelGGL(k_kick_drift, dim3(std::max(1, blocks_for(n_upper, 256))), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc,
+                       sh.own_count(), dt, sh.poison);
 }
 
 }  // namespace nbody

@@ -72,26 +72,6 @@ __device__ __forceinline__ int common_levels(unsigned long long a, unsigned long
     return (__clzll((long long)x) - 1) / 3;   // bit 63 is unused
 }
 
-// delta[k] for the boundary between sorted bodies k and k+1 (delta[n-1] = -1), opened[k], and the
-// per-body scan inputs
-__global__ __launch_bounds__(256) void k_tree_delta(const unsigned long long* __restrict__ keys,
-                                                    const int* __restrict__ ids, const float4* __restrict__ pos,
-                                                    const int* __restrict__ count, signed char* __restrict__ delta,
-                                                    int* __restrict__ emit_count, Sum4* __restrict__ sums,
-                                                    int* __restrict__ flags) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int n = *count;
-    if (k >= n) return;
-    const unsigned long long key = keys[k];
-    const int d_next = (k + 1 < n) ? common_levels(key, keys[k + 1]) : -1;
-    const int d_prev = (k > 0) ? common_levels(keys[k - 1], key) : -1;
-    if (d_next >= kLevels) atomicOr(flags, 1);  // two bodies share all 21 levels: too deep for this build
-    delta[k] = (signed char)d_next;
-    emit_count[k] = max(0, d_next - d_prev) + 1;  // opened cells + the leaf
-    const float4 p = pos[ids[k]];
-    sums[k] = Sum4{double(p.w), double(p.w) * double(p.x), double(p.w) * double(p.y), double(p.w) * double(p.z)};
-}
-
 // One thread per NODE (not per body: the first body of a big cell opens every level above it, and 15
 // cells x a 17-step binary search in one thread was the kernel's whole duration, 30 us).  Node idx
 // belongs to the body k with base[k] <= idx < base[k+1] (binary search); its t-th node is the cell of
@@ -101,7 +81,7 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
                                                    const int* __restrict__ count, const signed char* __restrict__ delta,
                                                    const int* __restrict__ base, const Sum4* __restrict__ incl,
                                                    float width, float4* __restrict__ nodes, int node_cap,
-                                                   int* __restrict__ order, int* __restrict__ out_info) {
+                                                   int* __restrict__ order, int* __restrict__ out_info, int want_hot) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
     if (n == 0) {  // the reference's empty root (barnes_hut.rs:145)
@@ -133,7 +113,7 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
     // NodeB::hot (octree_host.h): bodies in the grandparent cell = sorted bodies sharing the first depth-2 levels
     const int my_depth = (t < opened) ? d_prev + 1 + t : max(d_prev, d_next) + 1;
     int hot = n;
-    if (my_depth >= 2) {
+    if (want_hot && my_depth >= 2) {   // (two more binary searches per node, 5 us at N = 65 536: only for the walk that uses it)
         const int sh = 3 * (kLevels - (my_depth - 2));
         const unsigned long long lo_key = (key >> sh) << sh, hi_gp = lo_key | ((1ull << sh) - 1ull);
         int a = 0, b = k;               // first sorted body with key >= lo_key
@@ -178,9 +158,22 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
 // that body's path, each opened by the first sorted body that shares the prefix.
 __global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, const signed char* __restrict__ delta,
                                  const int* __restrict__ base, int n, int n_nodes, int n_split,
-                                 int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc) {
+                                 int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc,
+                                 const int* __restrict__ info, int* __restrict__ poison) {
     const int s = blockIdx.x;
     const int a = threadIdx.x;  // candidate ancestor depth
+    if (info) {   // unsynchronised step: the host has not seen this build's result
+        if (info[1] != 0) {   // the build needs the host (too deep / node array too small): stop everything that follows
+            if (poison && s == 0 && a == 0) atomicOr(poison, info[1]);
+            return;
+        }
+        n_nodes = info[0];
+        n = info[2];
+        if (n <= 0) {   // the reference's empty root: one segment boundary set
+            if (a == 0) { first[s] = (s == 0) ? 0 : n_nodes; if (s == n_split - 1) first[n_split] = n_nodes; n_anc[s] = 0; }
+            return;
+        }
+    }
     const int t = int((long long)n_nodes * s / n_split);
     if (a == 0) {
         first[s] = t;
@@ -209,97 +202,116 @@ __global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, co
     anc[s * max_anc + a] = base[kf] + (a - (dp + 1));
 }
 
-// ---- inclusive scan of Sum4 with a FIXED association order.  rocPRIM's decoupled look-back scan
-// combines the partial sums of earlier blocks in whatever grouping their completion order allows;
-// f64 addition is not associative, so a centre of mass would now and then differ in its last f32 bit
-// from one run to the next (seen: 1 node in 30 000, every few builds).  Three passes instead: block
-// totals (1024 items per block), a one-block scan of the totals, block-local scans with carry-in.
+// ---- the two scans of the build in three launches with a FIXED association order: per body k the exclusive
+// sum of emit_count (its first node's pre-order index) and the inclusive sum of {m, m x, m y, m z} in f64.
+// rocPRIM's decoupled look-back scan combines the partial sums of earlier blocks in whatever grouping their
+// completion order allows; f64 addition is not associative, so a centre of mass would now and then differ in its last
+// f32 bit from one run to the next (seen: 1 node in 30 000, every few builds).  Here: (1) k_tree_delta_totals computes
+// delta/emit_count/the Sum4 terms and each tile's totals (1 024 bodies per tile), (2) k_tree_scan adds up the totals of
+// the tiles before its own sequentially (tile order) and scans its tile locally (Hillis-Steele in LDS: a fixed
+// pattern).  One launch each -- the separate rocPRIM integer scan (2 launches) and the three-pass Sum4 scan of
+// round 1 cost 7 launches of ~5 us with k_tree_delta.
 constexpr int kScanThreads = 256, kScanItems = 4, kScanTile = kScanThreads * kScanItems;
 
 __device__ __forceinline__ Sum4 sum4_add(const Sum4& a, const Sum4& b) { return Sum4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
 
+struct ScanItem { Sum4 s; int c; };
+__device__ __forceinline__ ScanItem item_add(const ScanItem& a, const ScanItem& b) { return ScanItem{sum4_add(a.s, b.s), a.c + b.c}; }
+
 // inclusive scan of one value per thread over the block (Hillis-Steele in LDS: a fixed pattern)
 template <int THREADS>
-__device__ __forceinline__ Sum4 block_inclusive_scan(Sum4 v, Sum4* lds) {
+__device__ __forceinline__ ScanItem block_inclusive_scan(ScanItem v, ScanItem* lds) {
     const int t = threadIdx.x;
     lds[t] = v;
     __syncthreads();
     for (int off = 1; off < THREADS; off <<= 1) {
-        Sum4 add = Sum4{0.0, 0.0, 0.0, 0.0};
+        ScanItem add = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
         const bool has = t >= off;
         if (has) add = lds[t - off];
         __syncthreads();
-        if (has) { v = sum4_add(add, v); lds[t] = v; }
+        if (has) { v = item_add(add, v); lds[t] = v; }
         __syncthreads();
     }
     return v;
 }
 
-__global__ __launch_bounds__(kScanThreads) void k_sum4_block_totals(const Sum4* __restrict__ in, const int* __restrict__ count,
-                                                                     Sum4* __restrict__ totals) {
-    __shared__ Sum4 lds[kScanThreads];
+// per sorted body k: delta[k] (common levels with its right neighbour), emit_count[k] (cells it opens + its leaf), the
+// Sum4 term; per tile of kScanTile bodies: the totals of both
+__global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsigned long long* __restrict__ keys,
+                                                                     const int* __restrict__ ids, const float4* __restrict__ pos,
+                                                                     const int* __restrict__ count, signed char* __restrict__ delta,
+                                                                     int* __restrict__ emit_count, Sum4* __restrict__ sums,
+                                                                     int* __restrict__ flags, ScanItem* __restrict__ totals) {
+    __shared__ ScanItem lds[kScanThreads];
     const int n = *count;
-    const int i0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    Sum4 v = Sum4{0.0, 0.0, 0.0, 0.0};
+    const int k0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    ScanItem v = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
 #pragma unroll
-    for (int q = 0; q < kScanItems; ++q) if (i0 + q < n) v = sum4_add(v, in[i0 + q]);
+    for (int q = 0; q < kScanItems; ++q) {
+        const int k = k0 + q;
+        if (k >= n) break;
+        const unsigned long long key = keys[k];
+        const int d_next = (k + 1 < n) ? common_levels(key, keys[k + 1]) : -1;
+        const int d_prev = (k > 0) ? common_levels(keys[k - 1], key) : -1;
+        if (d_next >= kLevels) atomicOr(flags, 1);  // two bodies share all 21 levels: too deep for this build
+        delta[k] = (signed char)d_next;
+        const int ec = max(0, d_next - d_prev) + 1;  // opened cells + the leaf
+        emit_count[k] = ec;
+        const float4 p = pos[ids[k]];
+        const Sum4 t = Sum4{double(p.w), double(p.w) * double(p.x), double(p.w) * double(p.y), double(p.w) * double(p.z)};
+        sums[k] = t;
+        v = item_add(v, ScanItem{t, ec});
+    }
     v = block_inclusive_scan<kScanThreads>(v, lds);
     if (threadIdx.x == kScanThreads - 1) totals[blockIdx.x] = v;
 }
 
-// exclusive scan of the block totals, one workgroup; prefix[b] = sum of totals[0..b-1]
-__global__ __launch_bounds__(1024) void k_sum4_scan_totals(const Sum4* __restrict__ totals, int n_blocks,
-                                                            Sum4* __restrict__ prefix) {
-    __shared__ Sum4 lds[1024];
-    const int per = (n_blocks + 1023) / 1024;
-    const int b0 = threadIdx.x * per;
-    Sum4 v = Sum4{0.0, 0.0, 0.0, 0.0};
-    for (int q = 0; q < per; ++q) if (b0 + q < n_blocks) v = sum4_add(v, totals[b0 + q]);
-    const Sum4 incl = block_inclusive_scan<1024>(v, lds);
-    // exclusive prefix of this thread's first block = inclusive of the previous thread
-    __syncthreads();
-    lds[threadIdx.x] = incl;
-    __syncthreads();
-    Sum4 run = threadIdx.x > 0 ? lds[threadIdx.x - 1] : Sum4{0.0, 0.0, 0.0, 0.0};
-    for (int q = 0; q < per; ++q)
-        if (b0 + q < n_blocks) { prefix[b0 + q] = run; run = sum4_add(run, totals[b0 + q]); }
-}
-
-__global__ __launch_bounds__(kScanThreads) void k_sum4_block_scan(const Sum4* __restrict__ in, const int* __restrict__ count,
-                                                                   const Sum4* __restrict__ prefix, Sum4* __restrict__ out) {
-    __shared__ Sum4 lds[kScanThreads];
+// base[k] = exclusive scan of emit_count, incl[k] = inclusive scan of the Sum4 terms
+__global__ __launch_bounds__(kScanThreads) void k_tree_scan(const int* __restrict__ emit_count, const Sum4* __restrict__ sums,
+                                                            const int* __restrict__ count, const ScanItem* __restrict__ totals,
+                                                            int* __restrict__ base, Sum4* __restrict__ incl) {
+    __shared__ ScanItem lds[kScanThreads];
+    __shared__ ScanItem carry_s;
     const int n = *count;
-    const int i0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    Sum4 item[kScanItems];
-    Sum4 v = Sum4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < kScanItems; ++q) {
-        item[q] = (i0 + q < n) ? in[i0 + q] : Sum4{0.0, 0.0, 0.0, 0.0};
-        v = sum4_add(v, item[q]);
+    const int k0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    if (blockIdx.x * kScanTile >= n) return;
+    // the totals of the tiles before this one: thread t adds its run of consecutive tiles, the block scans the 256
+    // partial sums -- a fixed pattern that depends on the tile index only, so every build associates alike (one
+    // thread adding 64 totals one after the other was a 16 us chain of dependent loads)
+    {
+        const int before = int(blockIdx.x);
+        const int per = (before + kScanThreads - 1) / kScanThreads;
+        ScanItem run = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
+        for (int q = 0; q < per; ++q) {
+            const int b = int(threadIdx.x) * per + q;
+            if (b < before) run = item_add(run, totals[b]);
+        }
+        const ScanItem all = block_inclusive_scan<kScanThreads>(run, lds);
+        if (threadIdx.x == kScanThreads - 1) carry_s = all;
+        __syncthreads();
     }
-    const Sum4 incl = block_inclusive_scan<kScanThreads>(v, lds);
-    __syncthreads();
-    lds[threadIdx.x] = incl;
-    __syncthreads();
-    Sum4 run = sum4_add(prefix[blockIdx.x], threadIdx.x > 0 ? lds[threadIdx.x - 1] : Sum4{0.0, 0.0, 0.0, 0.0});
+    ScanItem item[kScanItems];
+    ScanItem v = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
 #pragma unroll
     for (int q = 0; q < kScanItems; ++q) {
-        run = sum4_add(run, item[q]);
-        if (i0 + q < n) out[i0 + q] = run;
+        item[q] = (k0 + q < n) ? ScanItem{sums[k0 + q], emit_count[k0 + q]} : ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
+        v = item_add(v, item[q]);
+    }
+    const ScanItem inc = block_inclusive_scan<kScanThreads>(v, lds);
+    __syncthreads();
+    lds[threadIdx.x] = inc;
+    __syncthreads();
+    ScanItem run = item_add(carry_s, threadIdx.x > 0 ? lds[threadIdx.x - 1] : ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0});
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) {
+        if (k0 + q < n) base[k0 + q] = run.c;
+        run = item_add(run, item[q]);
+        if (k0 + q < n) incl[k0 + q] = run.s;
     }
 }
 
-// bytes of scratch the three passes need for n_cap items
-size_t sum4_scan_tmp_bytes(size_t n_cap) { return 2 * ((n_cap + kScanTile - 1) / kScanTile + 1) * sizeof(Sum4); }
-
-void sum4_inclusive_scan(hipStream_t s, void* tmp, const Sum4* in, Sum4* out, const int* d_count, int n_upper) {
-    const int n_blocks = (n_upper + kScanTile - 1) / kScanTile;
-    Sum4* totals = static_cast<Sum4*>(tmp);
-    Sum4* prefix = totals + n_blocks + 1;
-    hipLaunchKernelGGL(k_sum4_block_totals, dim3(n_blocks), dim3(kScanThreads), 0, s, in, d_count, totals);
-    hipLaunchKernelGGL(k_sum4_scan_totals, dim3(1), dim3(1024), 0, s, totals, n_blocks, prefix);
-    hipLaunchKernelGGL(k_sum4_block_scan, dim3(n_blocks), dim3(kScanThreads), 0, s, in, d_count, prefix, out);
-}
+// bytes of scratch the passes need for n_cap bodies
+size_t sum4_scan_tmp_bytes(size_t n_cap) { return ((n_cap + kScanTile - 1) / kScanTile + 1) * sizeof(ScanItem); }
 
 // scratch at the start of the build workspace: whatever the rocPRIM sort / integer scan or the Sum4
 // scan asks for, whichever is largest
@@ -359,7 +371,7 @@ size_t tree_build_workspace_bytes(size_t n_cap) {
 // (1: deeper than 21 levels, 2: node_cap too small).  The caller reads it back before the walk.
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
-                        int* out_info, TreeDevWork* work) {
+                        int* out_info, TreeDevWork* work, int want_hot) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     char* p = static_cast<char*>(workspace);
     const size_t tmp_bytes = scratch_bytes(n_cap);
@@ -382,22 +394,23 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
         hipLaunchKernelGGL(k_tree_keys, grid, block, 0, s, pos, d_count, n, center[0], center[1], center[2], width, keys_in, ids_in, out_info);
         size_t tb = tmp_bytes;
         if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys, ids_in, ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
-        hipLaunchKernelGGL(k_tree_delta, grid, block, 0, s, keys, ids, pos, d_count, delta, emit_count, sums, out_info + 1);
-        tb = tmp_bytes;
-        if (rocprim::exclusive_scan(tmp, tb, emit_count, base, 0, size_t(n), rocprim::plus<int>(), s) != hipSuccess) return -1;
-        sum4_inclusive_scan(s, tmp, sums, incl, d_count, n);
+        const int n_tiles = (n + kScanTile - 1) / kScanTile;
+        ScanItem* totals = static_cast<ScanItem*>(tmp);   // (the sort is done with its scratch)
+        hipLaunchKernelGGL(k_tree_delta_totals, dim3(n_tiles), dim3(kScanThreads), 0, s, keys, ids, pos, d_count, delta, emit_count,
+                           sums, out_info + 1, totals);
+        hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, emit_count, sums, d_count, totals, base, incl);
     }
     // one thread per node; their number is known on the device only, so one per node the array can hold
     // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
     hipLaunchKernelGGL(k_tree_emit, dim3((std::max(1, node_cap) + 255) / 256), block, 0, s, keys, ids, pos, d_count, delta, base,
-                       incl, width, nodes, node_cap, order, out_info);
+                       incl, width, nodes, node_cap, order, out_info, want_hot);
     return 0;
 }
 
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
-                           int* n_anc, int* anc, int max_anc) {
+                           int* n_anc, int* anc, int max_anc, const int* info, int* poison) {
     hipLaunchKernelGGL(k_tree_split_anc, dim3(n_split), dim3(32), 0, s, work.keys, work.delta, work.base, n, n_nodes,
-                       n_split, first, n_anc, anc, max_anc);
+                       n_split, first, n_anc, anc, max_anc, info, poison);
 }
 
 // ---- level-order copy of the tree for the cooperative block walk (kernels_bh.hip k_bh_walk_block): the nodes sorted

@@ -118,6 +118,18 @@ struct NbodyHandle {
     uint64_t sym_pairs = 0;   // unordered pairs the rotation kernel covers at the current n_local
     size_t sym_pairs_n = 0;
 
+    // Barnes-Hut with the device build, single shard: steps are enqueued without reading anything back.  A build
+    // that needs the host (deeper than 21 levels, node array too small) sets a sticky flag on the device that turns
+    // every later state-changing kernel into a no-op; the host looks at it at the next synchronisation point and
+    // replays from the step that failed (resolve_async).
+    bool async_bh = false;
+    struct PendingStep { float dt; float elapsed_before; };
+    std::vector<PendingStep> pending;   // steps enqueued since the host last confirmed the device's progress
+    bool last_step_async = false;
+    bool host_tree_once = false;        // the next force pass builds its tree on the host (the replayed step)
+    int* d_poison = nullptr;            // [2] sticky flags, steps completed (Shard::poison)
+    int* h_poison = nullptr;            // pinned [8]: poison[2] + tree info[3]
+
     // diagnostics
     NbodyStats stats{};
     bool profiling = false;
@@ -408,10 +420,8 @@ int bf_forces(NbodyHandle* h) {
         h->tail_pending = true;
     }
     HIP_TRY(h, hipGetLastError());
-    if (tot > 0) {
-        h->stats.interactions += uint64_t(h->n_local) * uint64_t(tot - 1);
-        if (h->profiling) h->stats.force_kernel_interactions += timed;
-    }
+    // (NbodyStats::interactions is counted on the device from the live counts: Shard::inter)
+    if (tot > 0 && h->profiling) h->stats.force_kernel_interactions += timed;
     return NBODY_OK;
 }
 
@@ -436,6 +446,11 @@ int ensure_tree_dev(NbodyHandle* h, size_t nodes, size_t order) {
 // BarnesHutSimulation::update_forces (barnes_hut.rs:250-263): rebuild the tree from the current
 // positions, then one walk per body.
 int bh_walk_device_tree(NbodyHandle* h, bool* fell_back);
+int bh_walk_device_tree_async(NbodyHandle* h);
+int resolve_async(NbodyHandle* h);
+int step_end(NbodyHandle* h, float dt);
+int step_impl(NbodyHandle* h, float dt);
+extern "C" int nbody_bh_walk_debug;
 
 // strict math with the reference leaf rule walks with the reference's nested sums (bit-exact): a stack
 // of NBODY_MAX_TREE_DEPTH + 1 open cells per own body, 16 bytes each
@@ -513,12 +528,19 @@ int bh_forces(NbodyHandle* h) {
         int rc = exchange_wait(h);
         if (rc) return rc;
     }
-    if (h->cfg.tree_build == NBODY_TREE_DEVICE) {
+    h->last_step_async = false;
+    if (h->cfg.tree_build == NBODY_TREE_DEVICE && !h->host_tree_once) {
+        // no read-back at all: single shard, the plain or the strict walk (the experimental walks want the node count)
+        const bool plain_walk = h->cfg.math_mode == NBODY_MATH_STRICT || nbody_bh_walk_variant == 0;
+        if (h->async_bh && plain_walk && !nbody_bh_walk_debug) return bh_walk_device_tree_async(h);
+        int rc = resolve_async(h);
+        if (rc) return rc;
         bool fell_back = false;
-        int rc = bh_walk_device_tree(h, &fell_back);
+        rc = bh_walk_device_tree(h, &fell_back);
         if (rc || !fell_back) return rc;
         // deeper than 21 levels somewhere: this step's tree comes from the host build below
     }
+    h->host_tree_once = false;
     h->tree_on_device = false;
     auto t0 = clk::now();
     // positions of every segment (upper-bound counts) + the live counts, one sync
@@ -572,11 +594,11 @@ int bh_forces(NbodyHandle* h) {
         // ~3 waves per wave slot of the chip (256 CUs x 32), handed out heaviest first (nbody_bh_walk_order): the launch
         // lasts as long as its slowest wave, and smaller pieces started in the right order shorten that tail
         // (N = 65 536: 24 segments 0.310 ms, 8 segments 0.336 ms; tools/tune_bh_order.py)
-        int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((24576 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+        int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
         K = std::max(1, std::min(kMaxSplit, K));
         // strict math is the parity path: one segment, so every lane adds in the reference's order (bit-exact)
         if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;
-        while (K > 1 && size_t(K) * 16 > h->tree.n_nodes) K /= 2;
+        while (nbody_bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > h->tree.n_nodes) K /= 2;   // (a pinned split is taken as given)
         if (K > 1) {
             if (!h->d_split) {
                 HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
@@ -682,7 +704,7 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (nbody::build_octree_device(h->stream, tree_pos, tree_count, int(tot_upper), h->center, h->width,
                                        h->d_tree_ws, n_cap, h->d_nodes, int(h->d_node_cap), h->d_order, h->d_tree_info,
-                                       &work) != 0)
+                                       &work, nbody_bh_walk_variant == 3) != 0)
             return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(h->h_tree_info, h->d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -717,10 +739,10 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
         HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
         HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
     }
-    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((24576 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
     K = std::max(1, std::min(kMaxSplit, K));
     if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
-    while (K > 1 && K * 16 > n_nodes) K /= 2;
+    while (nbody_bh_walk_split <= 0 && K > 1 && K * 16 > n_nodes) K /= 2;
     if (n_order == 0) K = 1;
     nbody::TreeDev td;
     td.nodes = h->d_nodes; td.n_nodes = n_nodes;
@@ -760,6 +782,129 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     if (td.hot_cap > 0) HIP_TRY(h, hipMemcpyAsync(h->h_hot_info, h->d_hot_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
+}
+
+// The same force pass with nothing read back: the node count, the live body count and the build's flags stay on the
+// device (d_tree_info); the split points are placed by k_tree_split_anc from the device's node count, the walk takes
+// its body count from the device, and a build that needs the host poisons the run (see NbodyHandle::async_bh).
+int bh_walk_device_tree_async(NbodyHandle* h) {
+    Shard& sh = h->sh;
+    auto t1 = clk::now();
+    const size_t n_cap = size_t(sh.seg_cap);
+    if (h->tree_ws_cap < n_cap) {
+        if (h->d_tree_ws) (void)hipFree(h->d_tree_ws);
+        h->d_tree_ws = nullptr; h->tree_ws_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_tree_ws, nbody::tree_build_workspace_bytes(n_cap)));
+        h->tree_ws_cap = n_cap;
+    }
+    if (!h->d_tree_info) {
+        HIP_TRY(h, hipMalloc(&h->d_tree_info, 4 * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(&h->h_tree_info, 4 * sizeof(int), hipHostMallocDefault));
+    }
+    const size_t n_upper = h->n_local;   // an upper bound of the live count
+    int rc = ensure_tree_dev(h, std::max<size_t>(h->d_node_cap, 4 * n_upper + 64), n_upper);
+    if (rc) return rc;
+    if (h->pending.empty()) HIP_TRY(h, hipMemsetAsync(h->d_poison + 1, 0, sizeof(int), h->stream));   // steps completed: counted from here
+    nbody::TreeDevWork work;
+    if (nbody::build_octree_device(h->stream, sh.own_pos(), sh.own_count(), int(n_upper), h->center, h->width, h->d_tree_ws, n_cap,
+                                   h->d_nodes, int(h->d_node_cap), h->d_order, h->d_tree_info, &work, 0) != 0)
+        return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
+    HIP_TRY(h, hipGetLastError());
+    h->stats.tree_build_ms += ms_since(t1);   // (enqueue time: nothing is waited for)
+    h->tree_on_device = true;
+
+    constexpr int kMaxSplit = 64, kMaxAnc = 192;
+    if (!h->d_split) {
+        HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
+    }
+    const size_t groups = std::max<size_t>(1, (n_upper + 63) / 64);
+    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((16384 + groups - 1) / groups);
+    K = std::max(1, std::min(kMaxSplit, K));
+    if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
+    while (nbody_bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > n_upper) K /= 2;   // (a tree has at least as many nodes as bodies)
+    if (n_upper == 0) K = 1;
+    nbody::TreeDev td;
+    td.nodes = h->d_nodes; td.n_nodes = int(h->d_node_cap);   // (the plain walks end at the split points, not at n_nodes)
+    td.order = h->d_order; td.n_order = int(n_upper);
+    td.n_order_dev = h->d_tree_info + 2;
+    td.poison = h->d_poison;
+    td.n_split = K;
+    td.split_first = h->d_split;
+    td.split_n_anc = h->d_split + kMaxSplit + 1;
+    td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
+    nbody::launch_tree_split_anc(h->stream, work, int(n_upper), int(h->d_node_cap), K, h->d_split, h->d_split + kMaxSplit + 1,
+                                 h->d_split + kMaxSplit + 1 + kMaxSplit, kMaxAnc, h->d_tree_info, h->d_poison);
+    if (K > 1) {
+        const size_t need = size_t(K) * sh.seg_cap;
+        if (need > h->walk_planes_cap) {
+            if (h->d_walk_planes) (void)hipFree(h->d_walk_planes);
+            h->d_walk_planes = nullptr; h->walk_planes_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_walk_planes, need * sizeof(float4)));
+            h->walk_planes_cap = need;
+        }
+        td.split_planes = h->d_walk_planes;
+        td.split_stride = size_t(sh.seg_cap);
+    }
+    rc = ensure_nested_stack(h, &td);
+    if (rc) return rc;
+    {
+        ForceTimer t(h);
+        int kicked = 0;
+        nbody::launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2,
+                              h->cfg.math_mode == NBODY_MATH_FAST, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT,
+                              h->kick_pending ? &h->kick_dt : nullptr, &kicked);
+        if (kicked) h->kick_pending = false;  // the plane reduction applied the kick + half drift
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->last_step_async = true;
+    h->count_dirty = true;
+    return NBODY_OK;
+}
+
+// Where did the device get to?  Confirms the steps enqueued without read-back; if a build poisoned the run, finishes
+// the failed step with the host build (which handles any depth) and enqueues the rest again.
+int resolve_async(NbodyHandle* h) {
+    if (!h->async_bh) return NBODY_OK;
+    for (int round = 0; round < 1000000; ++round) {
+        HIP_TRY(h, hipMemcpyAsync(h->h_poison, h->d_poison, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (h->d_tree_info) HIP_TRY(h, hipMemcpyAsync(h->h_poison + 2, h->d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const int flags = h->h_poison[0], done = h->h_poison[1];
+        if (!flags) {
+            if (h->tree_on_device && h->d_tree_info) {   // what the last build produced
+                h->tree.n_nodes = size_t(h->h_poison[2]);
+                h->stats.tree_nodes = uint64_t(h->h_poison[2]);
+            }
+            h->pending.clear();
+            return NBODY_OK;
+        }
+        // poisoned: steps [0, done) are complete, step `done` has drifted and compacted, nothing after it has run
+        std::vector<NbodyHandle::PendingStep> rest;
+        if (size_t(done) < h->pending.size()) rest.assign(h->pending.begin() + done, h->pending.end());
+        h->pending.clear();
+        HIP_TRY(h, hipMemsetAsync(h->d_poison, 0, 2 * sizeof(int), h->stream));
+        if (flags & 2) {   // more nodes than the array holds: double it (the bound 4 n + 64 did not hold for this set)
+            int rc = ensure_tree_dev(h, 2 * h->d_node_cap + 64, h->n_local);
+            if (rc) return rc;
+        }
+        if (rest.empty()) {   // it was a force pass outside a step (nbody_update_forces): its caller runs it again
+            h->host_tree_once = true;
+            return NBODY_OK;
+        }
+        h->elapsed = rest[0].elapsed_before;
+        h->stats.steps -= rest.size();
+        h->host_tree_once = true;             // (cleared by the force pass that uses it)
+        int rc = sync_count(h);
+        if (rc) return rc;
+        rc = step_end(h, rest[0].dt);         // forces on the host-built tree, kick + half drift
+        if (rc) return rc;
+        for (size_t k = 1; k < rest.size(); ++k) {
+            rc = step_impl(h, rest[k].dt);    // (enqueued without read-back again: may poison again -> next round)
+            if (rc) return rc;
+        }
+    }
+    return fail(h, NBODY_ERR_INVALID, "resolve_async did not converge");
 }
 
 // ---- the partial sums other GPUs accumulated for the own bodies (symmetric scheme across shards)
@@ -819,7 +964,7 @@ int forces(NbodyHandle* h) {
 int step_begin(NbodyHandle* h, float dt) {
     if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
     nbody::launch_drift_half(h->stream, h->sh, int(h->n_local), dt, h->bnd);  // integrate_pre_force
-    nbody::launch_compact(h->stream, h->sh);                                   // retain
+    nbody::launch_compact(h->stream, h->sh, int(h->n_local));                 // retain
     h->count_dirty = true;
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
@@ -860,11 +1005,18 @@ int step_end(NbodyHandle* h, float dt) {
 }
 
 int step_impl(NbodyHandle* h, float dt) {
+    const float elapsed_before = h->elapsed;
     int rc = step_begin(h, dt);
     if (rc) return rc;
     rc = exchange_begin(h);   // the force pass waits for it where it first needs remote bodies
     if (rc) return rc;
-    return step_end(h, dt);
+    rc = step_end(h, dt);
+    if (rc) return rc;
+    if (h->last_step_async) {   // nothing was read back: remember the step until the device's progress is confirmed
+        h->pending.push_back(NbodyHandle::PendingStep{dt, elapsed_before});
+        if (h->pending.size() >= 4096) rc = resolve_async(h);
+    }
+    return rc;
 }
 
 void free_all(NbodyHandle* h) {
@@ -881,10 +1033,10 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
-    void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->d_aos,
+    void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->sh.tile_state, h->sh.epoch, h->sh.inter, h->d_poison, h->d_aos,
                    h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_walk, h->d_unified, h->d_hot, h->d_hot_info, h->d_bfs, h->d_bfs_ws, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info, h->h_hot_info};
+    void* host[] = {h->h_aos, h->h_pos, h->h_counts, h->h_counters, h->h_split, h->h_tree_info, h->h_hot_info, h->h_poison};
     for (void* p : host) if (p) (void)hipHostFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -939,6 +1091,19 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     CREATE_TRY(hipMemsetAsync(sh.seg_count, 0, sizeof(int) * sh.n_seg, h->stream));
     CREATE_TRY(hipMemsetAsync(sh.escaped, 0, sizeof(int), h->stream));
     CREATE_TRY(hipMemsetAsync(sh.keep, 1, cap, h->stream));
+    {
+        const size_t tiles = (cap + 1023) / 1024 + 1;
+        CREATE_TRY(hipMalloc(&sh.tile_state, tiles * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(sh.tile_state, 0, tiles * sizeof(unsigned long long), h->stream));
+        CREATE_TRY(hipMalloc(&sh.epoch, sizeof(int)));
+        CREATE_TRY(hipMemsetAsync(sh.epoch, 0, sizeof(int), h->stream));
+        CREATE_TRY(hipMemsetAsync(sh.epoch, 1, 1, h->stream));   // epoch = 1: the zeroed status words belong to no launch
+        CREATE_TRY(hipMalloc(&sh.inter, sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(sh.inter, 0, sizeof(unsigned long long), h->stream));
+        CREATE_TRY(hipMalloc(&h->d_poison, 2 * sizeof(int)));
+        CREATE_TRY(hipMemsetAsync(h->d_poison, 0, 2 * sizeof(int), h->stream));
+        CREATE_TRY(hipHostMalloc(&h->h_poison, 8 * sizeof(int), hipHostMallocDefault));
+    }
     CREATE_TRY(hipHostMalloc(&h->h_counts, sizeof(int) * sh.n_seg, hipHostMallocDefault));
     h->seg_count_host.assign(sh.n_seg, 0);
     if (cfg->method == NBODY_BARNES_HUT) {
@@ -956,6 +1121,12 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
+    {
+        const char* v = std::getenv("NBODY_BH_ASYNC");
+        h->async_bh = cfg->method == NBODY_BARNES_HUT && cfg->tree_build == NBODY_TREE_DEVICE && cfg->world_size == 1 &&
+                      !(v && v[0] == '0');
+        if (h->async_bh) sh.poison = h->d_poison;
+    }
     if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
     if (const char* v = std::getenv("NBODY_CROSS_SYM")) nbody_cross_sym = std::atoi(v);
     if (const char* v = std::getenv("NBODY_SYM_PACKED")) nbody_sym_packed = std::atoi(v);
@@ -991,6 +1162,8 @@ int nbody_clone(const NbodyHandle* src, NbodyHandle** out) {
     if (!src || !out) return fail(nullptr, NBODY_ERR_INVALID, "null argument");
     NbodyHandle* s = const_cast<NbodyHandle*>(src);
     int rc = use_device(s);
+    if (rc) return rc;
+    rc = resolve_async(s);
     if (rc) return rc;
     rc = sync_count(s);
     if (rc) return rc;
@@ -1029,6 +1202,8 @@ int nbody_upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     if (n > h->cfg.capacity) return fail(h, NBODY_ERR_CAPACITY, "more bodies than NbodyConfig.capacity");
     int rc = use_device(h);
     if (rc) return rc;
+    rc = resolve_async(h);
+    if (rc) return rc;
     Shard& sh = h->sh;
     const size_t G = size_t(sh.n_seg);
     const size_t blk = (n + G - 1) / G;  // contiguous index blocks keep the ascending-partner order
@@ -1056,6 +1231,8 @@ int nbody_download(NbodyHandle* h, void* aos, size_t cap, size_t stride, size_t*
     if (stride < 40 || stride % 4) return fail(h, NBODY_ERR_INVALID, "stride must be a multiple of 4 and >= 40 bytes");
     int rc = use_device(h);
     if (rc) return rc;
+    rc = resolve_async(h);
+    if (rc) return rc;
     rc = sync_count(h);
     if (rc) return rc;
     const size_t n = h->n_local;
@@ -1078,6 +1255,8 @@ int nbody_count(NbodyHandle* h, size_t* n_out) {
     if (!h || !n_out) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    rc = resolve_async(h);
+    if (rc) return rc;
     rc = sync_count(h);
     if (rc) return rc;
     *n_out = h->n_local;
@@ -1087,6 +1266,8 @@ int nbody_count(NbodyHandle* h, size_t* n_out) {
 int nbody_count_global(NbodyHandle* h, size_t* n_out) {
     if (!h || !n_out) return NBODY_ERR_INVALID;
     int rc = use_device(h);
+    if (rc) return rc;
+    rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
     if (rc) return rc;
@@ -1098,6 +1279,8 @@ int nbody_add_point(NbodyHandle* h, const void* particle) {
     if (!h || !particle) return NBODY_ERR_INVALID;
     if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "add_point is only supported on single-GPU handles");
     int rc = use_device(h);
+    if (rc) return rc;
+    rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
     if (rc) return rc;
@@ -1118,6 +1301,8 @@ int nbody_remove_point(NbodyHandle* h, size_t index) {
     if (!h) return NBODY_ERR_INVALID;
     if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "remove_point is only supported on single-GPU handles");
     int rc = use_device(h);
+    if (rc) return rc;
+    rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
     if (rc) return rc;
@@ -1187,9 +1372,16 @@ int nbody_update_forces(NbodyHandle* h) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->cfg.method == NBODY_BARNES_HUT && !h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+    rc = resolve_async(h);
+    if (rc) return rc;
     rc = exchange_begin(h);
     if (rc) return rc;
-    return forces(h);
+    rc = forces(h);
+    if (rc || !h->last_step_async) return rc;
+    h->last_step_async = false;
+    rc = resolve_async(h);              // (a force pass outside a step is confirmed at once)
+    if (rc || !h->host_tree_once) return rc;
+    return forces(h);                   // its build needed the host: once more, on the host-built tree
 }
 
 int nbody_elapsed(const NbodyHandle* h, float* out) {
@@ -1201,6 +1393,8 @@ int nbody_elapsed(const NbodyHandle* h, float* out) {
 int nbody_sync(NbodyHandle* h) {
     if (!h) return NBODY_ERR_INVALID;
     int rc = use_device(h);
+    if (rc) return rc;
+    rc = resolve_async(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NBODY_OK;
@@ -1216,8 +1410,16 @@ int nbody_stats(NbodyHandle* h, NbodyStats* out) {
     if (!h || !out) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    rc = resolve_async(h);
+    if (rc) return rc;
     rc = drain_events(h);
     if (rc) return rc;
+    if (h->cfg.method == NBODY_BRUTE_FORCE) {
+        unsigned long long* hv = reinterpret_cast<unsigned long long*>(h->h_poison + 4);   // (pinned scratch)
+        HIP_TRY(h, hipMemcpyAsync(hv, h->sh.inter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->stats.interactions = *hv;
+    }
     if (h->d_counters) {
         HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1235,11 +1437,14 @@ int nbody_reset_stats(NbodyHandle* h) {
     if (!h) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    rc = resolve_async(h);
+    if (rc) return rc;
     rc = drain_events(h);
     if (rc) return rc;
     uint64_t nodes = h->stats.tree_nodes;
     h->stats = NbodyStats{};
     h->stats.tree_nodes = nodes;
+    HIP_TRY(h, hipMemsetAsync(h->sh.inter, 0, sizeof(unsigned long long), h->stream));
     if (h->d_counters) {
         HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1250,6 +1455,8 @@ int nbody_reset_stats(NbodyHandle* h) {
 int nbody_energy(NbodyHandle* h, double* kinetic, double* potential) {
     if (!h) return NBODY_ERR_INVALID;
     int rc = use_device(h);
+    if (rc) return rc;
+    rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
     if (rc) return rc;
@@ -1278,6 +1485,12 @@ int nbody_energy(NbodyHandle* h, double* kinetic, double* potential) {
 int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* skip, size_t cap, size_t* n_nodes) {
     if (!h) return NBODY_ERR_INVALID;
     if (h->cfg.method != NBODY_BARNES_HUT) return fail(h, NBODY_ERR_INVALID, "not a Barnes-Hut handle");
+    {
+        int rc = use_device(h);
+        if (rc) return rc;
+        rc = resolve_async(h);
+        if (rc) return rc;
+    }
     const size_t n = h->tree.n_nodes;
     if (n_nodes) *n_nodes = n;
     if (!com_mass && !width && !skip) return NBODY_OK;
