@@ -56,9 +56,12 @@ enum { NBODY_MATH_STRICT = 0, /* sqrt, (d*d)*d, g/r^3, no FMA contraction, partn
 
 /* where the Barnes-Hut octree is built */
 enum { NBODY_TREE_HOST = 0,    /* host, every step (north_star; barnes_hut.rs:143-183 bit for bit) */
-       NBODY_TREE_DEVICE = 1 }; /* device: same cells and links, centre-of-mass
-                                   sums in a different order (f64 prefix sums), so node counts may differ
-                                   by a few parts in 1e4; single shard, <= 21 levels (else falls back to host) */
+       NBODY_TREE_DEVICE = 1,  /* device: same cells and links, centre-of-mass
+                                  sums in a different order (f64 prefix sums), so node counts may differ
+                                  by a few parts in 1e4; <= 21 levels (a deeper step is built on the host).
+                                  Single-shard handles enqueue their steps without any read-back */
+       NBODY_TREE_AUTO = 2 };  /* NBODY_MATH_FAST -> device, NBODY_MATH_STRICT -> host (the bit-exact path);
+                                  what the host-side mirrors pass by default */
 
 /* Barnes-Hut leaf semantics */
 enum {
@@ -78,7 +81,7 @@ typedef struct NbodyConfig {
     int32_t world_size;    /* number of shards (one process per GPU); 1 = single GPU */
     int32_t host_threads;  /* octree-build threads (the reference's `-t`, src/main.rs:34-35); 0 = all */
     uint64_t capacity;     /* max bodies over ALL shards (add_point may grow up to this) */
-    int32_t tree_build;    /* NBODY_TREE_HOST | NBODY_TREE_DEVICE (Barnes-Hut only) */
+    int32_t tree_build;    /* NBODY_TREE_HOST | NBODY_TREE_DEVICE | NBODY_TREE_AUTO (Barnes-Hut only) */
     int32_t reserved;      /* 0 */
 } NbodyConfig;
 

@@ -39,7 +39,7 @@ BRUTE_FORCE, BARNES_HUT = 0, 1
 STRICT, FAST = 0, 1
 LEAF_REFERENCE = 0   # src/manual: a leaf failing the opening test contributes nothing
 LEAF_DIRECT = 1      # the src/llm walk on the same tree: such a leaf is evaluated directly
-TREE_HOST, TREE_DEVICE = 0, 1
+TREE_HOST, TREE_DEVICE, TREE_AUTO = 0, 1, 2   # AUTO: fast math -> device build, strict -> host build
 COMM_ID_BYTES = 128
 
 #: PointParticle<f32,3>, #[repr(C)] (src/shared.rs:151-158)
@@ -199,7 +199,7 @@ class Simulation:
 
     def __init__(self, points: np.ndarray, center=(0.0, 0.0, 0.0), width: float = 1.0, *, method: int = BRUTE_FORCE,
                  math_mode: int = STRICT, capacity: int | None = None, device: int = -1, rank: int = 0,
-                 world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_HOST, leaf_mode: int = LEAF_REFERENCE,
+                 world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_AUTO, leaf_mode: int = LEAF_REFERENCE,
                  _handle=None):
         self._h = _H()
         if _handle is not None:

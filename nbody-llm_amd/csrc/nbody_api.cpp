@@ -1048,7 +1048,8 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (cfg->method != NBODY_BRUTE_FORCE && cfg->method != NBODY_BARNES_HUT) return fail(nullptr, NBODY_ERR_INVALID, "unknown method");
     if (cfg->math_mode != NBODY_MATH_STRICT && cfg->math_mode != NBODY_MATH_FAST) return fail(nullptr, NBODY_ERR_INVALID, "unknown math_mode");
     if (cfg->leaf_mode != NBODY_LEAF_REFERENCE && cfg->leaf_mode != NBODY_LEAF_DIRECT) return fail(nullptr, NBODY_ERR_INVALID, "unknown leaf_mode");
-    if (cfg->tree_build != NBODY_TREE_HOST && cfg->tree_build != NBODY_TREE_DEVICE) return fail(nullptr, NBODY_ERR_INVALID, "unknown tree_build");
+    if (cfg->tree_build != NBODY_TREE_HOST && cfg->tree_build != NBODY_TREE_DEVICE && cfg->tree_build != NBODY_TREE_AUTO)
+        return fail(nullptr, NBODY_ERR_INVALID, "unknown tree_build");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, NBODY_ERR_INVALID, "bad rank/world_size");
     if (cfg->capacity == 0 || cfg->capacity > (1ull << 30)) return fail(nullptr, NBODY_ERR_INVALID, "capacity must be in [1, 2^30]");
 
@@ -1064,6 +1065,9 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
 
     NbodyHandle* h = new NbodyHandle();
     h->cfg = *cfg;
+    if (h->cfg.tree_build == NBODY_TREE_AUTO)   // the bit-exact path keeps the reference's (host) build
+        h->cfg.tree_build = cfg->math_mode == NBODY_MATH_FAST ? NBODY_TREE_DEVICE : NBODY_TREE_HOST;
+    cfg = &h->cfg;
     h->device = dev;
     *out = nullptr;
     auto bail = [&](int rc) { g_create_err = h->err; free_all(h); return rc; };

@@ -16,14 +16,14 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: nbody_cli [-t threads] [-n points] [--method bh|bf] [--ic disc|plummer] [--steps K]\n"
-                 "                 [--math fast|strict] [--tree host|device] [--leaf reference|direct]\n"
+                 "                 [--math fast|strict] [--tree auto|host|device] [--leaf reference|direct]\n"
                  "                 [--dt x] [--g-soft x] [--theta2 x]\n"
                  "                 [--width w] [--seed s]\n");
 }
 
 int main(int argc, char** argv) {
     size_t threads = 0, num_points = 10000, steps = 1000;  // main.rs:33-38, :116
-    std::string method = "bh", ic = "disc", math = "fast", tree = "host", leaf = "reference";
+    std::string method = "bh", ic = "disc", math = "fast", tree = "auto", leaf = "reference";
     float dt = 3e-2f, g_soft = 0.02f, theta2 = 1.0f, width = 10.0f;  // main.rs:59,103-105
     unsigned long long seed = 20250523ull;
     bool width_set = false;
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
         nbody::Bounds bounds{{0.f, 0.f, 0.f}, width};
         if (method == "bf") sim.reset(new nbody::BruteForceSimulation(points, bounds, math_mode));
         else sim.reset(new nbody::BarnesHutSimulation(points, bounds, math_mode, 0, int(threads),
-                                                      tree == "device" ? NBODY_TREE_DEVICE : NBODY_TREE_HOST,
+                                                      tree == "device" ? NBODY_TREE_DEVICE : tree == "host" ? NBODY_TREE_HOST : NBODY_TREE_AUTO,
                                                       leaf == "direct" ? NBODY_LEAF_DIRECT : NBODY_LEAF_REFERENCE));
         sim->settings_mut().dt = dt;
         sim->settings_mut().g_soft = g_soft;

@@ -86,7 +86,7 @@ public:
 
 protected:
     Simulation(int method, const std::vector<PointParticle>& points, const Bounds& bounds, int math_mode,
-               size_t capacity, int host_threads, int tree_build = NBODY_TREE_HOST,
+               size_t capacity, int host_threads, int tree_build = NBODY_TREE_AUTO,
                int leaf_mode = NBODY_LEAF_REFERENCE) : bounds_(bounds) {
         NbodyConfig cfg{};
         cfg.struct_size = sizeof(cfg);
@@ -144,7 +144,7 @@ class BarnesHutSimulation : public Simulation {
 public:
     BarnesHutSimulation(const std::vector<PointParticle>& points, const Bounds& bounds,
                         int math_mode = NBODY_MATH_FAST, size_t capacity = 0, int host_threads = 0,
-                        int tree_build = NBODY_TREE_HOST, int leaf_mode = NBODY_LEAF_REFERENCE)
+                        int tree_build = NBODY_TREE_AUTO, int leaf_mode = NBODY_LEAF_REFERENCE)
         : Simulation(NBODY_BARNES_HUT, points, bounds, math_mode, capacity, host_threads, tree_build, leaf_mode) {}
     std::unique_ptr<BarnesHutSimulation> clone() const {
         return std::unique_ptr<BarnesHutSimulation>(new BarnesHutSimulation(clone_handle(), *this));

@@ -20,7 +20,7 @@ def test_direct_leaf_mode_counts_and_accelerations(gpu, orc, n, theta2, math):
     ref = ics.copy().astype(orc.P32)
     acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4, leaf_mode=1)
     with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT if math == "strict" else nb.FAST,
-                       leaf_mode=nb.LEAF_DIRECT) as sim:
+                       leaf_mode=nb.LEAF_DIRECT, tree_build=nb.TREE_HOST) as sim:
         sim.settings = nb.Settings(**sd)
         sim.update_forces()
         got = sim.get_points()
@@ -42,7 +42,7 @@ def test_direct_leaf_mode_is_accurate(gpu, orc):
     orc.bf_update_forces_rows(exact, dict(sd, g_soft=float(np.float32(sd["g_soft"]))), threads=8)
     errs = {}
     for mode in (nb.LEAF_REFERENCE, nb.LEAF_DIRECT):
-        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, leaf_mode=mode) as sim:
+        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, leaf_mode=mode, tree_build=nb.TREE_HOST) as sim:
             sim.settings = nb.Settings(**sd)
             sim.update_forces()
             a = sim.get_points()["acceleration"].astype(np.float64)

@@ -145,7 +145,7 @@ def test_fast_math_walk_same_nodes(gpu, orc):
     ics = nb.plummer(3000, seed=32)
     ref = ics.copy().astype(orc.P32)
     acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4)
-    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST) as sim:
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_HOST) as sim:
         sim.settings = st
         sim.update_forces()
         got = sim.get_points()
@@ -173,7 +173,7 @@ def test_alternative_walk_kernels_same_nodes(gpu, orc, variant, math, n, split):
     spl = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
     var.value, spl.value = variant, split
     try:
-        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT if math == "strict" else nb.FAST) as sim:
+        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT if math == "strict" else nb.FAST, tree_build=nb.TREE_HOST) as sim:
             sim.settings = st
             sim.update_forces()
             got = sim.get_points()
