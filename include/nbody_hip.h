@@ -14,8 +14,9 @@
  *     thread: src/main.rs:119-122, src/vis.rs:537-553);
  *   - the library owns all device memory; host buffers are caller-owned and only touched
  *     during the call;
- *   - bodies cross the boundary as `PointParticle<f32,3>` records (src/shared.rs:151-158,
- *     #[repr(C)]): 10 floats {pos[3], vel[3], acc[3], mass}, stride 40 bytes;
+ *   - bodies cross the boundary as `PointParticle<F,3>` records (src/shared.rs:151-158,
+ *     #[repr(C)]): 10 scalars {pos[3], vel[3], acc[3], mass} -- F = f32: 40 bytes (NbodyConfig.dtype =
+ *     NBODY_F32), F = f64: 80 bytes (NBODY_F64; the reference's own driver runs f64, src/main.rs:52-105);
  *   - there is no CPU fallback: without a HIP device nbody_create fails with NBODY_ERR_NO_DEVICE.
  */
 #ifndef NBODY_HIP_H
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 1
+#define NBODY_ABI_VERSION 2
 
 typedef struct NbodyHandle NbodyHandle;
 
@@ -71,6 +72,12 @@ enum {
                                  test is evaluated directly; force = d * (g*mass * (1/sqrt(r2+eps2))^3) */
 };
 
+/* the reference's `F: Float` (src/shared.rs:12-44) */
+enum { NBODY_F32 = 0,  /* PointParticle<f32,3>: every path of this library */
+       NBODY_F64 = 1 }; /* PointParticle<f64,3>: one shard, strict arithmetic (math_mode is ignored), Barnes-Hut with the
+                          host build; positions, velocities, accelerations and node counts bit-equal to the reference's
+                          rounding sequence in f64 (oracle/: the same templated restatement) */
+
 typedef struct NbodyConfig {
     uint32_t struct_size;  /* = sizeof(NbodyConfig) */
     int32_t method;        /* NBODY_BRUTE_FORCE | NBODY_BARNES_HUT */
@@ -82,7 +89,7 @@ typedef struct NbodyConfig {
     int32_t host_threads;  /* octree-build threads (the reference's `-t`, src/main.rs:34-35); 0 = all */
     uint64_t capacity;     /* max bodies over ALL shards (add_point may grow up to this) */
     int32_t tree_build;    /* NBODY_TREE_HOST | NBODY_TREE_DEVICE | NBODY_TREE_AUTO (Barnes-Hut only) */
-    int32_t reserved;      /* 0 */
+    int32_t dtype;         /* NBODY_F32 (0, the default) | NBODY_F64 */
 } NbodyConfig;
 
 typedef struct NbodyStats {
@@ -130,6 +137,11 @@ int nbody_set_settings(NbodyHandle* h, float g, float g_soft, float dt, float th
 int nbody_get_settings(const NbodyHandle* h, float* g, float* g_soft, float* dt, float* theta2);
 /* Bounds::new(center, width) (shared.rs:236-243). */
 int nbody_set_bounds(NbodyHandle* h, const float center[3], float width);
+/* The same for F = f64 (SimulationSettings<f64>, Bounds<f64, 3>).  Either set works on either kind of handle: the
+ * f32 entry points widen exactly, the f64 ones round to f32 on an f32 handle. */
+int nbody_set_settings_f64(NbodyHandle* h, double g, double g_soft, double dt, double theta2);
+int nbody_get_settings_f64(const NbodyHandle* h, double* g, double* g_soft, double* dt, double* theta2);
+int nbody_set_bounds_f64(NbodyHandle* h, const double center[3], double width);
 
 /* ---- stepping ------------------------------------------------------------------------------- */
 /* Simulation::init (brute_force.rs:47-50, barnes_hut.rs:229-236): elapsed = 0. */
@@ -137,6 +149,7 @@ int nbody_init(NbodyHandle* h);
 /* Simulation::step_by(dt) (brute_force.rs:84-90, barnes_hut.rs:265-271): half drift, retain
  * in-bounds bodies, forces, kick + half drift, elapsed += dt.  dt may be negative. */
 int nbody_step_by(NbodyHandle* h, float dt);
+int nbody_step_by_f64(NbodyHandle* h, double dt);
 /* k x Simulation::step() (shared.rs:86-88) with no host synchronisation in between (brute
  * force); returns after enqueueing.  Use nbody_sync before reading a host clock. */
 int nbody_steps(NbodyHandle* h, int k);
@@ -144,6 +157,7 @@ int nbody_steps(NbodyHandle* h, int k);
 int nbody_update_forces(NbodyHandle* h);
 /* Simulation::elapsed (shared.rs:94). */
 int nbody_elapsed(const NbodyHandle* h, float* out);
+int nbody_elapsed_f64(const NbodyHandle* h, double* out);
 /* Blocks until everything enqueued on the handle's stream has finished. */
 int nbody_sync(NbodyHandle* h);
 
@@ -157,6 +171,7 @@ int nbody_energy(NbodyHandle* h, double* kinetic, double* potential);
 /* Linearised octree of the last Barnes-Hut force pass: per node {com xyz, mass}, width, skip
  * index (first node after the subtree, depth-first pre-order).  Arrays may be NULL to count. */
 int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* skip, size_t cap, size_t* n_nodes);
+int nbody_tree_export_f64(NbodyHandle* h, double* com_mass, double* width, int32_t* skip, size_t cap, size_t* n_nodes); /* f64 handles */
 const char* nbody_last_error(const NbodyHandle* h); /* h may be NULL: last create/clone error */
 
 /* ---- multi-GPU (no reference counterpart) ------------------------ */
@@ -174,6 +189,9 @@ int nbody_ic_plummer(void* aos, size_t n, size_t stride_bytes, uint64_t seed);
 /* The reference's self-gravitating disc: 1 unit-mass star + n disc bodies (src/main.rs:52-89);
  * writes n+1 records. */
 int nbody_ic_disc(void* aos, size_t n_disc, size_t stride_bytes, uint64_t seed);
+/* the same sets as PointParticle<f64,3> records (80 bytes), unrounded */
+int nbody_ic_plummer_f64(void* aos, size_t n, size_t stride_bytes, uint64_t seed);
+int nbody_ic_disc_f64(void* aos, size_t n_disc, size_t stride_bytes, uint64_t seed);
 
 /* ---- test hooks: one sharded step with the exchange done by the caller ------------------------- */
 /* G handles of one process (rank r of world G, same device) stand in for G GPUs: step_begin on

@@ -47,6 +47,12 @@ PARTICLE_DTYPE = np.dtype(
     [("position", "<f4", 3), ("velocity", "<f4", 3), ("acceleration", "<f4", 3), ("mass", "<f4")]
 )
 assert PARTICLE_DTYPE.itemsize == 40
+#: PointParticle<f64,3> (the instantiation the reference's own driver uses, src/main.rs:52-105): NBODY_F64 handles
+PARTICLE_DTYPE64 = np.dtype(
+    [("position", "<f8", 3), ("velocity", "<f8", 3), ("acceleration", "<f8", 3), ("mass", "<f8")]
+)
+assert PARTICLE_DTYPE64.itemsize == 80
+F32, F64 = 0, 1
 
 #: every symbol include/nbody_hip.h declares (tests check the library exports all of them)
 DECLARED_SYMBOLS = [
@@ -58,6 +64,8 @@ DECLARED_SYMBOLS = [
     "nbody_ic_disc", "nbody_host_build_tree", "nbody_abi_version", "nbody_device_count",
     "nbody_debug_step_begin", "nbody_debug_import_segment", "nbody_debug_step_forces",
     "nbody_debug_import_partials", "nbody_debug_step_end", "nbody_host_cross_plan",
+    "nbody_set_settings_f64", "nbody_get_settings_f64", "nbody_set_bounds_f64", "nbody_step_by_f64", "nbody_elapsed_f64",
+    "nbody_tree_export_f64", "nbody_ic_plummer_f64", "nbody_ic_disc_f64",
 ]
 
 
@@ -65,7 +73,7 @@ class NbodyConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("method", C.c_int32), ("math_mode", C.c_int32), ("leaf_mode", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("host_threads", C.c_int32),
-        ("capacity", C.c_uint64), ("tree_build", C.c_int32), ("reserved", C.c_int32),
+        ("capacity", C.c_uint64), ("tree_build", C.c_int32), ("dtype", C.c_int32),
     ]
 
 
@@ -127,6 +135,16 @@ _sig("nbody_debug_import_partials", _i, _H, _H)
 _sig("nbody_debug_step_end", _i, _H, _f)
 _sig("nbody_host_cross_plan", _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_void_p, C.POINTER(_i),
      C.c_void_p)
+_d = C.c_double
+_pd = C.POINTER(C.c_double)
+_sig("nbody_set_settings_f64", _i, _H, _d, _d, _d, _d)
+_sig("nbody_get_settings_f64", _i, _H, _pd, _pd, _pd, _pd)
+_sig("nbody_set_bounds_f64", _i, _H, _pd, _d)
+_sig("nbody_step_by_f64", _i, _H, _d)
+_sig("nbody_elapsed_f64", _i, _H, _pd)
+_sig("nbody_tree_export_f64", _i, _H, C.c_void_p, C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz))
+_sig("nbody_ic_plummer_f64", _i, C.c_void_p, _sz, _sz, C.c_uint64)
+_sig("nbody_ic_disc_f64", _i, C.c_void_p, _sz, _sz, C.c_uint64)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
 
@@ -141,8 +159,14 @@ def device_count() -> int:
     return int(lib.nbody_device_count())
 
 
-def plummer(n: int, seed: int = 20250523) -> np.ndarray:
-    """Plummer sphere in Henon units as PointParticle records (host side, f64 -> f32)."""
+def plummer(n: int, seed: int = 20250523, f64: bool = False) -> np.ndarray:
+    """Plummer sphere in Henon units as PointParticle records (host side; generated in f64, rounded to f32 unless f64)."""
+    if f64:
+        out = np.zeros(n, dtype=PARTICLE_DTYPE64)
+        rc = lib.nbody_ic_plummer_f64(out.ctypes.data, n, 80, seed)
+        if rc:
+            raise NbodyError(rc, "nbody_ic_plummer_f64")
+        return out
     out = np.zeros(n, dtype=PARTICLE_DTYPE)
     rc = lib.nbody_ic_plummer(out.ctypes.data, n, 40, seed)
     if rc:
@@ -150,8 +174,14 @@ def plummer(n: int, seed: int = 20250523) -> np.ndarray:
     return out
 
 
-def disc(n_disc: int, seed: int = 20250523) -> np.ndarray:
+def disc(n_disc: int, seed: int = 20250523, f64: bool = False) -> np.ndarray:
     """The reference's self-gravitating disc (src/main.rs:52-89): 1 star + n_disc bodies."""
+    if f64:
+        out = np.zeros(n_disc + 1, dtype=PARTICLE_DTYPE64)
+        rc = lib.nbody_ic_disc_f64(out.ctypes.data, n_disc, 80, seed)
+        if rc:
+            raise NbodyError(rc, "nbody_ic_disc_f64")
+        return out
     out = np.zeros(n_disc + 1, dtype=PARTICLE_DTYPE)
     rc = lib.nbody_ic_disc(out.ctypes.data, n_disc, 40, seed)
     if rc:
@@ -200,20 +230,25 @@ class Simulation:
     def __init__(self, points: np.ndarray, center=(0.0, 0.0, 0.0), width: float = 1.0, *, method: int = BRUTE_FORCE,
                  math_mode: int = STRICT, capacity: int | None = None, device: int = -1, rank: int = 0,
                  world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_AUTO, leaf_mode: int = LEAF_REFERENCE,
-                 _handle=None):
+                 f64: bool | None = None, _handle=None, _f64: bool = False):
         self._h = _H()
+        self.f64 = bool(_f64)
         if _handle is not None:
             self._h = _handle
             return
-        points = np.ascontiguousarray(points, dtype=PARTICLE_DTYPE)
+        # F = f64 when the records are PointParticle<f64,3> (or asked for): NBODY_F64 handle, 80-byte records
+        self.f64 = bool(f64) if f64 is not None else (getattr(points, "dtype", None) == PARTICLE_DTYPE64)
+        self.dtype = PARTICLE_DTYPE64 if self.f64 else PARTICLE_DTYPE
+        points = np.ascontiguousarray(points, dtype=self.dtype)
         cfg = NbodyConfig(C.sizeof(NbodyConfig), method, math_mode, leaf_mode, device, rank, world_size,
-                          host_threads, int(capacity if capacity is not None else max(1, points.shape[0])), tree_build, 0)
+                          host_threads, int(capacity if capacity is not None else max(1, points.shape[0])), tree_build,
+                          F64 if self.f64 else F32)
         rc = lib.nbody_create(C.byref(cfg), C.byref(self._h))
         if rc:
             self._h = _H()
             raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
-        self._check(lib.nbody_set_bounds(self._h, (C.c_float * 3)(*[float(x) for x in center]), float(width)))
-        self._check(lib.nbody_upload(self._h, points.ctypes.data, points.shape[0], 40))
+        self.set_bounds(center, width)
+        self._check(lib.nbody_upload(self._h, points.ctypes.data, points.shape[0], self.dtype.itemsize))
 
     # -- plumbing
     def _check(self, rc: int):
@@ -248,13 +283,13 @@ class Simulation:
         self._check(lib.nbody_steps(self._h, int(k)))
 
     def step_by(self, dt: float):
-        self._check(lib.nbody_step_by(self._h, float(dt)))
+        self._check(lib.nbody_step_by_f64(self._h, float(dt)) if self.f64 else lib.nbody_step_by(self._h, float(dt)))
 
     def update_forces(self):
         self._check(lib.nbody_update_forces(self._h))
 
     def add_point(self, particle: np.ndarray):
-        p = np.ascontiguousarray(particle, dtype=PARTICLE_DTYPE).reshape(1)
+        p = np.ascontiguousarray(particle, dtype=self.dtype).reshape(1)
         self._check(lib.nbody_add_point(self._h, p.ctypes.data))
 
     def remove_point(self, index: int):
@@ -263,8 +298,8 @@ class Simulation:
     def get_points(self) -> np.ndarray:
         n = C.c_size_t(0)
         self._check(lib.nbody_count(self._h, C.byref(n)))
-        out = np.zeros(n.value, dtype=PARTICLE_DTYPE)
-        self._check(lib.nbody_download(self._h, out.ctypes.data, n.value, 40, C.byref(n)))
+        out = np.zeros(n.value, dtype=self.dtype)
+        self._check(lib.nbody_download(self._h, out.ctypes.data, n.value, self.dtype.itemsize, C.byref(n)))
         return out[: n.value]
 
     def __len__(self) -> int:
@@ -278,29 +313,45 @@ class Simulation:
         return int(n.value)
 
     def elapsed(self) -> float:
+        if self.f64:
+            d = C.c_double(0)
+            self._check(lib.nbody_elapsed_f64(self._h, C.byref(d)))
+            return float(d.value)
         v = C.c_float(0)
         self._check(lib.nbody_elapsed(self._h, C.byref(v)))
         return float(v.value)
 
     @property
     def settings(self) -> Settings:
+        if self.f64:
+            g, e, dt, t2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+            self._check(lib.nbody_get_settings_f64(self._h, C.byref(g), C.byref(e), C.byref(dt), C.byref(t2)))
+            return Settings(g.value, e.value, dt.value, t2.value)
         g, e, dt, t2 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
         self._check(lib.nbody_get_settings(self._h, C.byref(g), C.byref(e), C.byref(dt), C.byref(t2)))
         return Settings(g.value, e.value, dt.value, t2.value)
 
     @settings.setter
     def settings(self, s: Settings):
-        self._check(lib.nbody_set_settings(self._h, float(s.g), float(s.g_soft), float(s.dt), float(s.theta2)))
+        if self.f64:
+            self._check(lib.nbody_set_settings_f64(self._h, float(s.g), float(s.g_soft), float(s.dt), float(s.theta2)))
+        else:
+            self._check(lib.nbody_set_settings(self._h, float(s.g), float(s.g_soft), float(s.dt), float(s.theta2)))
 
     def set_bounds(self, center, width: float):
-        self._check(lib.nbody_set_bounds(self._h, (C.c_float * 3)(*[float(x) for x in center]), float(width)))
+        if self.f64:
+            self._check(lib.nbody_set_bounds_f64(self._h, (C.c_double * 3)(*[float(x) for x in center]), float(width)))
+        else:
+            self._check(lib.nbody_set_bounds(self._h, (C.c_float * 3)(*[float(x) for x in center]), float(width)))
 
     def clone(self) -> "Simulation":
         h = _H()
         rc = lib.nbody_clone(self._h, C.byref(h))
         if rc:
             raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
-        return Simulation(None, _handle=h)
+        twin = Simulation(None, _handle=h, _f64=self.f64)
+        twin.dtype = self.dtype
+        return twin
 
     # -- diagnostics / multi-GPU
     def sync(self):
@@ -324,12 +375,14 @@ class Simulation:
 
     def tree(self):
         n = C.c_size_t(0)
-        self._check(lib.nbody_tree_export(self._h, None, None, None, 0, C.byref(n)))
+        export = lib.nbody_tree_export_f64 if self.f64 else lib.nbody_tree_export
+        ft = np.float64 if self.f64 else np.float32
+        self._check(export(self._h, None, None, None, 0, C.byref(n)))
         m = n.value
-        com = np.zeros((m, 4), np.float32)
-        w = np.zeros(m, np.float32)
+        com = np.zeros((m, 4), ft)
+        w = np.zeros(m, ft)
         skip = np.zeros(m, np.int32)
-        self._check(lib.nbody_tree_export(self._h, com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, C.byref(n)))
+        self._check(export(self._h, com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, C.byref(n)))
         return dict(com_mass=com, width=w, skip=skip)
 
     def local_range(self) -> tuple[int, int]:

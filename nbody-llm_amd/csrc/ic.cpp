@@ -37,7 +37,13 @@ struct Xoshiro256ss {  // xoshiro256** seeded by splitmix64 (public-domain algor
     double uniform() { return double(next() >> 11) * (1.0 / 9007199254740992.0); }  // [0, 1)
 };
 
-void put(void* aos, size_t k, size_t stride, const double pos[3], const double vel[3], double m) {
+// records are PointParticle<f32,3> (40 B) or, `wide`, PointParticle<f64,3> (80 B, the values unrounded)
+void put(void* aos, size_t k, size_t stride, const double pos[3], const double vel[3], double m, bool wide) {
+    if (wide) {
+        double rec[10] = {pos[0], pos[1], pos[2], vel[0], vel[1], vel[2], 0.0, 0.0, 0.0, m};
+        std::memcpy(static_cast<char*>(aos) + k * stride, rec, sizeof(rec));
+        return;
+    }
     float rec[10] = {float(pos[0]), float(pos[1]), float(pos[2]), float(vel[0]), float(vel[1]), float(vel[2]),
                      0.f, 0.f, 0.f, float(m)};
     std::memcpy(static_cast<char*>(aos) + k * stride, rec, sizeof(rec));
@@ -45,8 +51,8 @@ void put(void* aos, size_t k, size_t stride, const double pos[3], const double v
 
 }  // namespace
 
-extern "C" int nbody_ic_plummer(void* aos, size_t n, size_t stride, uint64_t seed) {
-    if (!aos || stride < 40) return NBODY_ERR_INVALID;
+static int ic_plummer(void* aos, size_t n, size_t stride, uint64_t seed, bool wide) {
+    if (!aos || stride < (wide ? 80u : 40u)) return NBODY_ERR_INVALID;
     if (n == 0) return NBODY_OK;
     const double kPi = 3.14159265358979323846;
     const double len = 3.0 * kPi / 16.0;  // Henon units: G = M = 1, E = -1/4
@@ -85,17 +91,20 @@ extern "C" int nbody_ic_plummer(void* aos, size_t n, size_t stride, uint64_t see
     for (size_t k = 0; k < n; ++k) {
         double p[3] = {P[3 * k] - cp[0], P[3 * k + 1] - cp[1], P[3 * k + 2] - cp[2]};
         double v[3] = {V[3 * k] - cv[0], V[3 * k + 1] - cv[1], V[3 * k + 2] - cv[2]};
-        put(aos, k, stride, p, v, m);
+        put(aos, k, stride, p, v, m, wide);
     }
     return NBODY_OK;
 }
 
-extern "C" int nbody_ic_disc(void* aos, size_t n_disc, size_t stride, uint64_t seed) {
-    if (!aos || stride < 40) return NBODY_ERR_INVALID;
+extern "C" int nbody_ic_plummer(void* aos, size_t n, size_t stride, uint64_t seed) { return ic_plummer(aos, n, stride, seed, false); }
+extern "C" int nbody_ic_plummer_f64(void* aos, size_t n, size_t stride, uint64_t seed) { return ic_plummer(aos, n, stride, seed, true); }
+
+static int ic_disc(void* aos, size_t n_disc, size_t stride, uint64_t seed, bool wide) {
+    if (!aos || stride < (wide ? 80u : 40u)) return NBODY_ERR_INVALID;
     const double kPi = 3.14159265358979323846;
     Xoshiro256ss rng(seed);
     const double zero[3] = {0, 0, 0};
-    put(aos, 0, stride, zero, zero, 1.0);              // main.rs:52-57
+    put(aos, 0, stride, zero, zero, 1.0, wide);        // main.rs:52-57
     const double box_width = 10.0;                      // :59
     const double disc_mass = 2e-1;                      // :61
     const double disc_max = box_width / 2.0 / 1.2;      // :62
@@ -110,7 +119,10 @@ extern "C" int nbody_ic_disc(void* aos, size_t n_disc, size_t stride, uint64_t s
         double vkep = std::sqrt(mu * 1.0 / a);
         double pos[3] = {x, y, z};
         double vel[3] = {vkep * std::sin(phi), -vkep * std::cos(phi), 0.0};
-        put(aos, k + 1, stride, pos, vel, disc_mass / double(n_disc));
+        put(aos, k + 1, stride, pos, vel, disc_mass / double(n_disc), wide);
     }
     return NBODY_OK;
 }
+
+extern "C" int nbody_ic_disc(void* aos, size_t n_disc, size_t stride, uint64_t seed) { return ic_disc(aos, n_disc, stride, seed, false); }
+extern "C" int nbody_ic_disc_f64(void* aos, size_t n_disc, size_t stride, uint64_t seed) { return ic_disc(aos, n_disc, stride, seed, true); }

@@ -5,12 +5,8 @@
 //   K1 drift_half -> K4 compact (retain) -> [exchange] -> K2 | (host octree + K5) -> K3 kick_drift
 // Everything is enqueued on the handle's own stream; the brute-force path never synchronises
 // with the host inside nbody_steps, the Barnes-Hut path must (the octree is built on the host).
-#include "../../include/nbody_hip.h"
-#include "kernels.h"
-#include "octree_host.h"
-
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include "nbody_handle.h"
+#include "nbody_f64.h"
 
 #include <algorithm>
 #include <chrono>
@@ -32,120 +28,6 @@ extern "C" int nbody_bh_walk_variant;
 extern "C" int nbody_bh_walk_lds_block;
 extern "C" int nbody_bh_hot_cap = 2048;  // fast walk, variant 3: node records staged in LDS per workgroup (32 B each)
 extern "C" int nbody_cross_sym = 1;  // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided
-
-using nbody::BoundsF;
-using nbody::Shard;
-
-struct NbodyHandle {
-    NbodyConfig cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    Shard sh;
-    float g = 1.0f, g_soft = 0.0f, dt = 1e-3f, theta2 = 0.5f;  // shared.rs:69-78
-    float center[3] = {0.f, 0.f, 0.f};
-    float width = 0.f;
-    BoundsF bnd{};
-    bool bounds_set = false;
-    float elapsed = 0.f;
-
-    size_t n_local = 0;        // host view of the own body count (an upper bound while count_dirty)
-    bool count_dirty = false;  // drift may have dropped bodies since n_local was read
-    std::vector<int> seg_count_host;  // host view of every segment's count (upper bounds likewise)
-    size_t first_global = 0, n_at_upload = 0;
-
-    float* d_aos = nullptr;    // device staging for PointParticle records
-    float* h_aos = nullptr;    // pinned host staging
-    size_t aos_cap = 0;        // records
-
-    // Barnes-Hut
-    std::unique_ptr<nbody::WorkerPool> pool;
-    nbody::HostTree tree;
-    nbody::BuildScratch tree_scratch;
-    float4* d_nodes = nullptr;  // 2 float4 per node: {com, mass}, {width^2, skip, width, leaf body}
-    int* d_order = nullptr;
-    size_t d_node_cap = 0, d_order_cap = 0;
-    float* h_pos = nullptr;    // pinned: all segments' positions
-    int* h_counts = nullptr;   // pinned: all segments' counts
-    std::vector<int32_t> own_order;
-    void* d_tree_ws = nullptr;   // device-build workspace (keys, sort buffers, scans)
-    void* d_tree_cat = nullptr;  // sharded device build: concatenated positions, own-order list
-    float4* d_nested_stack = nullptr;  // strict Barnes-Hut: per-lane stack of open cells (k_bh_walk_nested)
-    size_t nested_cap = 0;
-    size_t tree_ws_cap = 0;      // bodies it is sized for
-    int* d_tree_info = nullptr;  // [3] node count, flags, bodies in the tree
-    int* h_tree_info = nullptr;  // pinned
-    bool tree_on_device = false; // the last tree was built on the device (export copies it back)
-    int* d_split = nullptr;      // [33 + 32 + 32*192] ints: first[], n_anc[], anc[][192]
-    int* h_split = nullptr;      // pinned mirror
-    float4* d_walk_planes = nullptr;
-    size_t walk_planes_cap = 0;  // float4 entries
-    // fast walk with the most-visited records in LDS (kernels_bh.hip, variant 3)
-    float4* d_walk = nullptr;    // [walk_cap + 1] records with explicit links
-    int* d_unified = nullptr;    // [walk_cap + 1]
-    size_t walk_cap = 0;         // nodes
-    float4* d_bfs = nullptr;     // cooperative block walk (variant 5): level-order copy of the nodes
-    void* d_bfs_ws = nullptr;
-    size_t bfs_cap = 0;          // nodes
-    float4* d_hot = nullptr;     // [hot_cap] records
-    int hot_cap = 0;
-    int* d_hot_info = nullptr;   // [2] slot counter, nodes flagged by the last pass
-    int* h_hot_info = nullptr;   // pinned; refreshed after every walk, read after the next step's first sync
-    int hot_threshold = 0;       // NodeB::hot >= this -> staged; steered so that ~hot_cap nodes qualify
-    size_t hot_threshold_n = 0;  // body count the threshold was initialised for
-    unsigned long long* d_counters = nullptr;  // [NBODY_WALK_COUNTER_SLOTS][2] accepted, visited (summed on read)
-    unsigned long long* h_counters = nullptr;  // pinned
-
-    // symmetric all-pairs kernel (fast math, single shard, n >= kSymMinBodies)
-    nbody::SymPlan sym_plan;
-    int* d_sym_bounds = nullptr;
-    float4* d_planes = nullptr;
-    size_t planes_cap = 0;  // float4 entries
-    int sym_waves = 0;
-    // symmetric scheme across shards (kernels_bf_cross.hip)
-    nbody::CrossPlan cross;
-    bool cross_on = false;
-    int4* d_cross_slices = nullptr;
-    size_t cross_slices_cap = 0;
-    float4* d_xplanes = nullptr;   // [parts.n][A][plane_stride] travelling-side sums for other shards' bodies
-    float4* d_send = nullptr;      // [parts.n][plane_stride] what goes back to their owners
-    size_t xplanes_cap = 0, send_cap = 0;
-    int recv_plane0 = 0;           // first plane that receives the other shards' partial sums
-    bool tail_pending = false;     // the plane reduction has not been launched yet (waits for the partials)
-    bool partials_in_flight = false;
-    hipEvent_t ev_partials_ready = nullptr, ev_partials_done = nullptr;
-    bool kick_pending = false;  // step_end asks the force pass to fuse integrate_after_force if it can
-    float kick_dt = 0.f;
-    uint64_t sym_pairs = 0;   // unordered pairs the rotation kernel covers at the current n_local
-    size_t sym_pairs_n = 0;
-
-    // Barnes-Hut with the device build, single shard: steps are enqueued without reading anything back.  A build
-    // that needs the host (deeper than 21 levels, node array too small) sets a sticky flag on the device that turns
-    // every later state-changing kernel into a no-op; the host looks at it at the next synchronisation point and
-    // replays from the step that failed (resolve_async).
-    bool async_bh = false;
-    struct PendingStep { float dt; float elapsed_before; };
-    std::vector<PendingStep> pending;   // steps enqueued since the host last confirmed the device's progress
-    bool last_step_async = false;
-    bool host_tree_once = false;        // the next force pass builds its tree on the host (the replayed step)
-    int* d_poison = nullptr;            // [2] sticky flags, steps completed (Shard::poison)
-    int* h_poison = nullptr;            // pinned [8]: poison[2] + tree info[3]
-
-    // diagnostics
-    NbodyStats stats{};
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
-    double* d_energy = nullptr;
-    size_t energy_blocks = 0;
-
-    // multi-GPU
-    ncclComm_t comm = nullptr;
-    bool comm_ready = false;
-    hipStream_t comm_stream = nullptr;   // the exchange runs here, beside the own-shard force kernel
-    hipEvent_t ev_drifted = nullptr, ev_gathered = nullptr;
-    bool exchange_in_flight = false;
-
-    std::string err;
-};
 
 static thread_local std::string g_create_err;
 
@@ -452,16 +334,20 @@ int step_end(NbodyHandle* h, float dt);
 int step_impl(NbodyHandle* h, float dt);
 extern "C" int nbody_bh_walk_debug;
 
-// strict math with the reference leaf rule walks with the reference's nested sums (bit-exact): a stack
-// of NBODY_MAX_TREE_DEPTH + 1 open cells per own body, 16 bytes each
+// strict math with the reference leaf rule walks with the reference's nested sums (bit-exact): per own body a stack
+// of the open cells on its path, 16 bytes each -- as many levels as the tree is deep (the device build stops at 21;
+// the host build reports its depth), not NBODY_MAX_TREE_DEPTH of them (13 GB at N = 2^22)
 int ensure_nested_stack(NbodyHandle* h, nbody::TreeDev* td) {
     if (h->cfg.math_mode != NBODY_MATH_STRICT || h->cfg.leaf_mode != NBODY_LEAF_REFERENCE) return NBODY_OK;
     const size_t lanes = (size_t(h->sh.seg_cap) + 255) / 256 * 256;
-    if (lanes > h->nested_cap) {
+    const int levels = (h->tree_on_device ? 22 : h->tree.max_depth) + 2;
+    if (lanes > h->nested_cap || levels > h->nested_levels) {
         if (h->d_nested_stack) (void)hipFree(h->d_nested_stack);
-        h->d_nested_stack = nullptr; h->nested_cap = 0;
-        HIP_TRY(h, hipMalloc(&h->d_nested_stack, lanes * size_t(NBODY_MAX_TREE_DEPTH + 1) * sizeof(float4)));
+        h->d_nested_stack = nullptr; h->nested_cap = 0; h->nested_levels = 0;
+        const int lv = std::max(levels + 8, 32);
+        HIP_TRY(h, hipMalloc(&h->d_nested_stack, lanes * size_t(lv) * sizeof(float4)));
         h->nested_cap = lanes;
+        h->nested_levels = lv;
     }
     td->nested_stack = h->d_nested_stack;
     td->nested_stride = h->nested_cap;
@@ -1033,6 +919,7 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
+    nbody64::destroy(h);
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->sh.tile_state, h->sh.epoch, h->sh.inter, h->d_poison, h->d_aos,
                    h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_walk, h->d_unified, h->d_hot, h->d_hot_info, h->d_bfs, h->d_bfs_ws, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -1052,6 +939,8 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
         return fail(nullptr, NBODY_ERR_INVALID, "unknown tree_build");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, NBODY_ERR_INVALID, "bad rank/world_size");
     if (cfg->capacity == 0 || cfg->capacity > (1ull << 30)) return fail(nullptr, NBODY_ERR_INVALID, "capacity must be in [1, 2^30]");
+    if (cfg->dtype != NBODY_F32 && cfg->dtype != NBODY_F64) return fail(nullptr, NBODY_ERR_INVALID, "unknown dtype");
+    if (cfg->dtype == NBODY_F64 && cfg->world_size != 1) return fail(nullptr, NBODY_ERR_INVALID, "f64 handles are single-shard (world_size must be 1)");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1067,6 +956,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     h->cfg = *cfg;
     if (h->cfg.tree_build == NBODY_TREE_AUTO)   // the bit-exact path keeps the reference's (host) build
         h->cfg.tree_build = cfg->math_mode == NBODY_MATH_FAST ? NBODY_TREE_DEVICE : NBODY_TREE_HOST;
+    if (h->cfg.dtype == NBODY_F64) { h->cfg.tree_build = NBODY_TREE_HOST; h->cfg.math_mode = NBODY_MATH_STRICT; }   // what F = f64 runs
     cfg = &h->cfg;
     h->device = dev;
     *out = nullptr;
@@ -1078,6 +968,22 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     } while (0)
     CREATE_TRY(hipSetDevice(dev));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (cfg->dtype == NBODY_F64) {   // the state of an f64 handle lives in nbody64::State
+        CREATE_TRY(hipHostMalloc(&h->h_poison, 8 * sizeof(int), hipHostMallocDefault));
+        if (cfg->method == NBODY_BARNES_HUT) {
+            int threads = cfg->host_threads > 0 ? cfg->host_threads : std::min(16, std::max(1, int(std::thread::hardware_concurrency()) - 2));
+            h->pool.reset(new nbody::WorkerPool(std::max(1, threads)));
+            CREATE_TRY(hipMalloc(&h->d_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long)));
+            CREATE_TRY(hipMemsetAsync(h->d_counters, 0, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), h->stream));
+            CREATE_TRY(hipHostMalloc(&h->h_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), hipHostMallocDefault));
+        }
+        h->sh.n_seg = 1; h->sh.my_seg = 0; h->sh.seg_cap = int(cfg->capacity);
+        h->seg_count_host.assign(1, 0);
+        int rc64 = nbody64::create(h);
+        if (rc64) return bail(rc64);
+        *out = h;
+        return NBODY_OK;
+    }
     Shard& sh = h->sh;
     sh.n_seg = cfg->world_size;
     sh.my_seg = cfg->rank;
@@ -1169,11 +1075,17 @@ int nbody_clone(const NbodyHandle* src, NbodyHandle** out) {
     if (rc) return rc;
     rc = resolve_async(s);
     if (rc) return rc;
-    rc = sync_count(s);
+    if (!s->f64) rc = sync_count(s);
     if (rc) return rc;
     NbodyHandle* h = nullptr;
     rc = create_impl(&src->cfg, &h);
     if (rc) return rc;
+    if (src->f64) {
+        rc = nbody64::clone_state(s, h);
+        if (rc) { g_create_err = h->err; free_all(h); return rc; }
+        *out = h;
+        return NBODY_OK;
+    }
     const Shard& a = src->sh;
     const size_t cap = size_t(a.seg_cap);
     hipError_t e = hipStreamSynchronize(s->stream);
@@ -1206,6 +1118,7 @@ int nbody_upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     if (n > h->cfg.capacity) return fail(h, NBODY_ERR_CAPACITY, "more bodies than NbodyConfig.capacity");
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return (n && !aos) ? NBODY_ERR_INVALID : nbody64::upload(h, aos, n, stride);
     rc = resolve_async(h);
     if (rc) return rc;
     Shard& sh = h->sh;
@@ -1235,6 +1148,7 @@ int nbody_download(NbodyHandle* h, void* aos, size_t cap, size_t stride, size_t*
     if (stride < 40 || stride % 4) return fail(h, NBODY_ERR_INVALID, "stride must be a multiple of 4 and >= 40 bytes");
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::download(h, aos, cap, stride, n_out);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1259,6 +1173,7 @@ int nbody_count(NbodyHandle* h, size_t* n_out) {
     if (!h || !n_out) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::count(h, n_out);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1271,6 +1186,7 @@ int nbody_count_global(NbodyHandle* h, size_t* n_out) {
     if (!h || !n_out) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::count(h, n_out);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1284,6 +1200,7 @@ int nbody_add_point(NbodyHandle* h, const void* particle) {
     if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "add_point is only supported on single-GPU handles");
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::add_point(h, particle);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1306,6 +1223,7 @@ int nbody_remove_point(NbodyHandle* h, size_t index) {
     if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "remove_point is only supported on single-GPU handles");
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::remove_point(h, index);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1324,12 +1242,22 @@ int nbody_remove_point(NbodyHandle* h, size_t index) {
 
 int nbody_set_settings(NbodyHandle* h, float g, float g_soft, float dt, float theta2) {
     if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) return nbody64::set_settings(h, double(g), double(g_soft), double(dt), double(theta2));
     h->g = g; h->g_soft = g_soft; h->dt = dt; h->theta2 = theta2;
     return NBODY_OK;
 }
 
 int nbody_get_settings(const NbodyHandle* h, float* g, float* g_soft, float* dt, float* theta2) {
     if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) {
+        double a, b, c, d;
+        nbody64::get_settings(h, &a, &b, &c, &d);
+        if (g) *g = float(a);
+        if (g_soft) *g_soft = float(b);
+        if (dt) *dt = float(c);
+        if (theta2) *theta2 = float(d);
+        return NBODY_OK;
+    }
     if (g) *g = h->g;
     if (g_soft) *g_soft = h->g_soft;
     if (dt) *dt = h->dt;
@@ -1337,8 +1265,35 @@ int nbody_get_settings(const NbodyHandle* h, float* g, float* g_soft, float* dt,
     return NBODY_OK;
 }
 
+int nbody_set_settings_f64(NbodyHandle* h, double g, double g_soft, double dt, double theta2) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) return nbody64::set_settings(h, g, g_soft, dt, theta2);
+    return nbody_set_settings(h, float(g), float(g_soft), float(dt), float(theta2));
+}
+
+int nbody_get_settings_f64(const NbodyHandle* h, double* g, double* g_soft, double* dt, double* theta2) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) return nbody64::get_settings(h, g, g_soft, dt, theta2);
+    if (g) *g = double(h->g);
+    if (g_soft) *g_soft = double(h->g_soft);
+    if (dt) *dt = double(h->dt);
+    if (theta2) *theta2 = double(h->theta2);
+    return NBODY_OK;
+}
+
+int nbody_set_bounds_f64(NbodyHandle* h, const double center[3], double width) {
+    if (!h || !center) return NBODY_ERR_INVALID;
+    if (h->f64) return nbody64::set_bounds(h, center, width);
+    const float c[3] = {float(center[0]), float(center[1]), float(center[2])};
+    return nbody_set_bounds(h, c, float(width));
+}
+
 int nbody_set_bounds(NbodyHandle* h, const float center[3], float width) {
     if (!h || !center) return NBODY_ERR_INVALID;
+    if (h->f64) {
+        const double c[3] = {double(center[0]), double(center[1]), double(center[2])};
+        return nbody64::set_bounds(h, c, double(width));
+    }
     std::memcpy(h->center, center, sizeof(h->center));
     h->width = width;
     compute_bounds(h);
@@ -1348,6 +1303,7 @@ int nbody_set_bounds(NbodyHandle* h, const float center[3], float width) {
 
 int nbody_init(NbodyHandle* h) {
     if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) return nbody64::init(h);
     h->elapsed = 0.f;  // brute_force.rs:49; the reference's BH init also builds a tree that the
                        // first update_forces rebuilds before any use (barnes_hut.rs:232-235, 251-254)
     return NBODY_OK;
@@ -1357,13 +1313,23 @@ int nbody_step_by(NbodyHandle* h, float dt) {
     if (!h) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::step_by(h, double(dt));
     return step_impl(h, dt);
+}
+
+int nbody_step_by_f64(NbodyHandle* h, double dt) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->f64) return nbody64::step_by(h, dt);
+    return step_impl(h, float(dt));
 }
 
 int nbody_steps(NbodyHandle* h, int k) {
     if (!h || k < 0) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::steps(h, k);
     for (int i = 0; i < k; ++i) {
         rc = step_impl(h, h->dt);  // Simulation::step, shared.rs:86-88
         if (rc) return rc;
@@ -1375,6 +1341,7 @@ int nbody_update_forces(NbodyHandle* h) {
     if (!h) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::update_forces(h);
     if (h->cfg.method == NBODY_BARNES_HUT && !h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
     rc = resolve_async(h);
     if (rc) return rc;
@@ -1390,7 +1357,13 @@ int nbody_update_forces(NbodyHandle* h) {
 
 int nbody_elapsed(const NbodyHandle* h, float* out) {
     if (!h || !out) return NBODY_ERR_INVALID;
-    *out = h->elapsed;
+    *out = h->f64 ? float(nbody64::elapsed(h)) : h->elapsed;
+    return NBODY_OK;
+}
+
+int nbody_elapsed_f64(const NbodyHandle* h, double* out) {
+    if (!h || !out) return NBODY_ERR_INVALID;
+    *out = h->f64 ? nbody64::elapsed(h) : double(h->elapsed);
     return NBODY_OK;
 }
 
@@ -1418,6 +1391,7 @@ int nbody_stats(NbodyHandle* h, NbodyStats* out) {
     if (rc) return rc;
     rc = drain_events(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::stats(h, out);
     if (h->cfg.method == NBODY_BRUTE_FORCE) {
         unsigned long long* hv = reinterpret_cast<unsigned long long*>(h->h_poison + 4);   // (pinned scratch)
         HIP_TRY(h, hipMemcpyAsync(hv, h->sh.inter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -1448,7 +1422,8 @@ int nbody_reset_stats(NbodyHandle* h) {
     uint64_t nodes = h->stats.tree_nodes;
     h->stats = NbodyStats{};
     h->stats.tree_nodes = nodes;
-    HIP_TRY(h, hipMemsetAsync(h->sh.inter, 0, sizeof(unsigned long long), h->stream));
+    if (h->f64) { rc = nbody64::reset_stats(h); if (rc) return rc; }
+    else HIP_TRY(h, hipMemsetAsync(h->sh.inter, 0, sizeof(unsigned long long), h->stream));
     if (h->d_counters) {
         HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1460,6 +1435,7 @@ int nbody_energy(NbodyHandle* h, double* kinetic, double* potential) {
     if (!h) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->f64) return nbody64::energy(h, kinetic, potential);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1489,6 +1465,10 @@ int nbody_energy(NbodyHandle* h, double* kinetic, double* potential) {
 int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* skip, size_t cap, size_t* n_nodes) {
     if (!h) return NBODY_ERR_INVALID;
     if (h->cfg.method != NBODY_BARNES_HUT) return fail(h, NBODY_ERR_INVALID, "not a Barnes-Hut handle");
+    if (h->f64) {
+        if (com_mass || width) return fail(h, NBODY_ERR_INVALID, "f64 handle: use nbody_tree_export_f64");
+        return nbody64::tree_export(h, nullptr, nullptr, skip, cap, n_nodes);
+    }
     {
         int rc = use_device(h);
         if (rc) return rc;
@@ -1515,6 +1495,13 @@ int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* sk
     return NBODY_OK;
 }
 
+int nbody_tree_export_f64(NbodyHandle* h, double* com_mass, double* width, int32_t* skip, size_t cap, size_t* n_nodes) {
+    if (!h) return NBODY_ERR_INVALID;
+    if (h->cfg.method != NBODY_BARNES_HUT) return fail(h, NBODY_ERR_INVALID, "not a Barnes-Hut handle");
+    if (!h->f64) return fail(h, NBODY_ERR_INVALID, "f32 handle: use nbody_tree_export");
+    return nbody64::tree_export(h, com_mass, width, skip, cap, n_nodes);
+}
+
 int nbody_comm_unique_id(void* id_bytes) {
     if (!id_bytes) return NBODY_ERR_INVALID;
     static_assert(sizeof(ncclUniqueId) <= NBODY_COMM_ID_BYTES, "ncclUniqueId larger than NBODY_COMM_ID_BYTES");
@@ -1528,6 +1515,7 @@ int nbody_comm_unique_id(void* id_bytes) {
 
 int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
     if (!h || !id_bytes) return NBODY_ERR_INVALID;
+    if (h->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     int rc = use_device(h);
     if (rc) return rc;
     if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; h->comm_ready = false; }
@@ -1558,12 +1546,14 @@ int nbody_local_range(const NbodyHandle* h, size_t* first, size_t* count) {
 // is what nbody_step_by does around the RCCL all-gather; only the transport differs.
 int nbody_debug_step_begin(NbodyHandle* h, float dt) {
     if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     int rc = use_device(h);
     return rc ? rc : step_begin(h, dt);
 }
 
 int nbody_debug_import_segment(NbodyHandle* h, NbodyHandle* peer) {
     if (!h || !peer) return NBODY_ERR_INVALID;
+    if (h->f64 || peer->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     if (h->sh.n_seg != peer->sh.n_seg || h->sh.seg_cap != peer->sh.seg_cap) return fail(h, NBODY_ERR_INVALID, "peer has a different sharding");
     int rc = use_device(h);
     if (rc) return rc;
@@ -1578,6 +1568,7 @@ int nbody_debug_import_segment(NbodyHandle* h, NbodyHandle* peer) {
 
 int nbody_debug_step_forces(NbodyHandle* h, float dt) {
     if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     int rc = use_device(h);
     return rc ? rc : step_forces(h, dt);
 }
@@ -1586,6 +1577,7 @@ int nbody_debug_step_forces(NbodyHandle* h, float dt) {
 // shard's bodies, into the plane reserved for that sender
 int nbody_debug_import_partials(NbodyHandle* h, NbodyHandle* peer) {
     if (!h || !peer) return NBODY_ERR_INVALID;
+    if (h->f64 || peer->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     int rc = use_device(h);
     if (rc) return rc;
     if (!(h->cross_on && h->tail_pending)) return NBODY_OK;   // this force pass exchanges nothing
@@ -1605,6 +1597,7 @@ int nbody_debug_import_partials(NbodyHandle* h, NbodyHandle* peer) {
 
 int nbody_debug_step_end(NbodyHandle* h, float dt) {
     if (!h) return NBODY_ERR_INVALID;
+    if (h->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     int rc = use_device(h);
     return rc ? rc : step_finish(h, dt);
 }

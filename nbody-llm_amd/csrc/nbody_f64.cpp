@@ -1,0 +1,461 @@
+// nbody_f64.cpp -- host orchestration of an F = f64 handle: the reference's `Simulation<f64, 3, PointParticle<f64,3>, _>`
+// (the instantiation its own driver uses, src/main.rs:52-105).  One shard, strict arithmetic, the octree built on the
+// host in f64 (octree_host.cpp, the same stable 8-way partition as for f32): positions, velocities, accelerations
+// and node counts equal the oracle's f64 instantiation bit for bit.  Bodies cross the boundary as 80-byte records.
+#include "nbody_f64.h"
+#include "kernels_f64.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace nbody64 {
+
+struct State {
+    Dev d;
+    double g = 1.0, g_soft = 0.0, dt = 1e-3, theta2 = 0.5;   // shared.rs:69-78
+    double center[3] = {0.0, 0.0, 0.0};
+    double width = 0.0;
+    Bounds64 bnd{};
+    bool bounds_set = false;
+    double elapsed = 0.0;
+    size_t n_local = 0;        // host view of the body count (an upper bound while count_dirty)
+    bool count_dirty = false;
+    int* h_count = nullptr;    // pinned [2]
+    double* d_aos = nullptr;   // staging for PointParticle<f64,3> records
+    double* h_aos = nullptr;   // pinned
+    size_t aos_cap = 0;
+    // Barnes-Hut
+    nbody::HostTreeT<double> tree;
+    nbody::BuildScratchT<double> scratch;
+    Node64* d_nodes = nullptr;
+    size_t node_cap = 0;
+    int* d_order = nullptr;
+    size_t order_cap = 0;
+    double* h_pos = nullptr;   // pinned [4 * cap]
+    Open64* d_stack = nullptr; // nested walk: [levels][lanes]
+    size_t stack_lanes = 0;
+    int stack_levels = 0;
+    double* d_energy = nullptr;
+    size_t energy_blocks = 0;
+};
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+int fail(NbodyHandle* h, int code, const std::string& msg) {
+    h->err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, NBODY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+void* pinned_alloc(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void pinned_free(void* p) { (void)hipHostFree(p); }
+
+int ensure_aos(NbodyHandle* h, State& s, size_t records) {
+    if (records <= s.aos_cap) return NBODY_OK;
+    if (s.d_aos) (void)hipFree(s.d_aos);
+    if (s.h_aos) (void)hipHostFree(s.h_aos);
+    s.d_aos = nullptr; s.h_aos = nullptr; s.aos_cap = 0;
+    HIP_TRY(h, hipMalloc(&s.d_aos, records * 10 * sizeof(double)));
+    HIP_TRY(h, hipHostMalloc(&s.h_aos, records * 10 * sizeof(double), hipHostMallocDefault));
+    s.aos_cap = records;
+    return NBODY_OK;
+}
+
+int sync_count(NbodyHandle* h, State& s) {
+    if (!s.count_dirty) return NBODY_OK;
+    HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    s.n_local = size_t(s.h_count[0]);
+    s.count_dirty = false;
+    return NBODY_OK;
+}
+
+int push_count(NbodyHandle* h, State& s) {
+    s.h_count[0] = int(s.n_local);
+    HIP_TRY(h, hipMemcpyAsync(s.d.count, s.h_count, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+
+struct ForceTimer {  // HIP events around a force-kernel launch, on the launch stream (as in nbody_api.cpp)
+    NbodyHandle* h;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    explicit ForceTimer(NbodyHandle* hh) : h(hh) {
+        if (!h->profiling) return;
+        if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
+        else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) { ev = {nullptr, nullptr}; return; }
+        (void)hipEventRecord(ev.first, h->stream);
+    }
+    ~ForceTimer() {
+        if (!ev.first) return;
+        (void)hipEventRecord(ev.second, h->stream);
+        h->ev_pending.push_back(ev);
+    }
+};
+
+int bf_forces(NbodyHandle* h, State& s) {
+    const double eps2 = s.g_soft * s.g_soft;  // brute_force.rs:69
+    {
+        ForceTimer t(h);
+        launch_bf_strict(h->stream, s.d, int(s.n_local), s.g, eps2);
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (h->profiling && s.n_local > 0) h->stats.force_kernel_interactions += uint64_t(s.n_local) * uint64_t(s.n_local - 1);
+    return NBODY_OK;
+}
+
+// BarnesHutSimulation::update_forces (barnes_hut.rs:250-263): rebuild the tree (host, f64), one walk per body
+int bh_forces(NbodyHandle* h, State& s) {
+    auto t0 = clk::now();
+    if (s.n_local) HIP_TRY(h, hipMemcpyAsync(s.h_pos, s.d.pos, s.n_local * sizeof(double4), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    s.n_local = size_t(s.h_count[0]);
+    s.count_dirty = false;
+    const double copy_ms = ms_since(t0);
+    auto t1 = clk::now();
+    int cnt = int(s.n_local);
+    nbody::build_octree<double>(s.h_pos, 1, s.d.cap, &cnt, s.center, s.width, *h->pool, s.scratch, s.tree);
+    if (s.tree.too_deep) return fail(h, NBODY_ERR_TREE_DEPTH, "octree deeper than NBODY_MAX_TREE_DEPTH (coincident bodies?)");
+    h->stats.tree_build_ms += ms_since(t1);
+    h->stats.tree_nodes = s.tree.n_nodes;
+    auto t2 = clk::now();
+    if (s.tree.n_nodes > s.node_cap) {
+        if (s.d_nodes) (void)hipFree(s.d_nodes);
+        s.d_nodes = nullptr; s.node_cap = 0;
+        const size_t cap = s.tree.n_nodes + s.tree.n_nodes / 4 + 1024;
+        HIP_TRY(h, hipMalloc(&s.d_nodes, cap * sizeof(Node64)));
+        s.node_cap = cap;
+    }
+    if (s.tree.n_order > s.order_cap) {
+        if (s.d_order) (void)hipFree(s.d_order);
+        s.d_order = nullptr; s.order_cap = 0;
+        const size_t cap = s.tree.n_order + s.tree.n_order / 4 + 1024;
+        HIP_TRY(h, hipMalloc(&s.d_order, cap * sizeof(int)));
+        s.order_cap = cap;
+    }
+    static_assert(sizeof(nbody::NodeRecT<double>) == sizeof(Node64), "host and device node records must agree");
+    HIP_TRY(h, hipMemcpyAsync(s.d_nodes, s.tree.nodes, s.tree.n_nodes * sizeof(Node64), hipMemcpyHostToDevice, h->stream));
+    if (s.tree.n_order) HIP_TRY(h, hipMemcpyAsync(s.d_order, s.tree.order, s.tree.n_order * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->stats.tree_copy_ms += copy_ms + ms_since(t2);
+    const bool direct = h->cfg.leaf_mode == NBODY_LEAF_DIRECT;
+    if (!direct) {   // the nested sums' stack: one entry per open cell on the lane's path, i.e. the tree's depth
+        const size_t lanes = (size_t(s.d.cap) + 255) / 256 * 256;
+        const int levels = s.tree.max_depth + 2;
+        if (lanes > s.stack_lanes || levels > s.stack_levels) {
+            if (s.d_stack) (void)hipFree(s.d_stack);
+            s.d_stack = nullptr; s.stack_lanes = 0; s.stack_levels = 0;
+            const int lv = std::max(levels + 8, 32);
+            HIP_TRY(h, hipMalloc(&s.d_stack, lanes * size_t(lv) * sizeof(Open64)));
+            s.stack_lanes = lanes; s.stack_levels = lv;
+        }
+    }
+    {
+        ForceTimer t(h);
+        launch_bh_walk(h->stream, s.d, s.d_nodes, int(s.tree.n_nodes), s.d_order, int(s.tree.n_order), s.g, s.g_soft * s.g_soft, s.theta2,
+                       h->d_counters, direct ? 1 : 0, s.d_stack, s.stack_lanes);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+int forces(NbodyHandle* h, State& s) { return h->cfg.method == NBODY_BARNES_HUT ? bh_forces(h, s) : bf_forces(h, s); }
+
+int step_impl(NbodyHandle* h, State& s, double dt) {
+    if (!s.bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+    launch_drift_half(h->stream, s.d, int(s.n_local), dt, s.bnd);   // integrate_pre_force
+    launch_compact(h->stream, s.d, int(s.n_local));                 // retain
+    s.count_dirty = true;
+    HIP_TRY(h, hipGetLastError());
+    int rc = forces(h, s);                                          // update_forces
+    if (rc) return rc;
+    launch_kick_drift(h->stream, s.d, int(s.n_local), dt);          // integrate_after_force
+    HIP_TRY(h, hipGetLastError());
+    s.elapsed += dt;                                                // elapsed += dt
+    h->stats.steps += 1;
+    return NBODY_OK;
+}
+
+}  // namespace
+
+int create(NbodyHandle* h) {
+    State* sp = new State();
+    h->f64 = sp;
+    State& s = *sp;
+    const size_t cap = size_t(h->cfg.capacity);
+    s.d.cap = int(cap);
+    HIP_TRY(h, hipMalloc(&s.d.pos, cap * sizeof(double4)));
+    HIP_TRY(h, hipMalloc(&s.d.vel, cap * sizeof(double4)));
+    HIP_TRY(h, hipMalloc(&s.d.acc, cap * sizeof(double4)));
+    HIP_TRY(h, hipMalloc(&s.d.count, sizeof(int)));
+    HIP_TRY(h, hipMalloc(&s.d.escaped, sizeof(int)));
+    HIP_TRY(h, hipMalloc(&s.d.keep, cap));
+    const size_t tiles = (cap + 1023) / 1024 + 1;
+    HIP_TRY(h, hipMalloc(&s.d.tile_state, tiles * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMalloc(&s.d.epoch, sizeof(int)));
+    HIP_TRY(h, hipMalloc(&s.d.inter, sizeof(unsigned long long)));
+    HIP_TRY(h, hipMemsetAsync(s.d.pos, 0, cap * sizeof(double4), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.vel, 0, cap * sizeof(double4), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.acc, 0, cap * sizeof(double4), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.count, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.escaped, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.keep, 1, cap, h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.tile_state, 0, tiles * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.epoch, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.epoch, 1, 1, h->stream));   // epoch = 1
+    HIP_TRY(h, hipMemsetAsync(s.d.inter, 0, sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipHostMalloc(&s.h_count, 2 * sizeof(int), hipHostMallocDefault));
+    if (h->cfg.method == NBODY_BARNES_HUT) {
+        s.tree.alloc = pinned_alloc;
+        s.tree.release = pinned_free;
+        HIP_TRY(h, hipHostMalloc(&s.h_pos, cap * sizeof(double4), hipHostMallocDefault));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+
+void destroy(NbodyHandle* h) {
+    State* s = h->f64;
+    if (!s) return;
+    s->tree.clear();
+    void* dev[] = {s->d.pos, s->d.vel, s->d.acc, s->d.count, s->d.escaped, s->d.keep, s->d.tile_state, s->d.epoch, s->d.inter,
+                   s->d_aos, s->d_nodes, s->d_order, s->d_stack, s->d_energy};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* host[] = {s->h_count, s->h_aos, s->h_pos};
+    for (void* p : host) if (p) (void)hipHostFree(p);
+    delete s;
+    h->f64 = nullptr;
+}
+
+int clone_state(NbodyHandle* src, NbodyHandle* dst) {
+    State& a = *src->f64;
+    State& b = *dst->f64;
+    int rc = sync_count(src, a);
+    if (rc) return rc;
+    const size_t cap = size_t(a.d.cap);
+    HIP_TRY(dst, hipStreamSynchronize(src->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d.pos, a.d.pos, cap * sizeof(double4), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d.vel, a.d.vel, cap * sizeof(double4), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d.acc, a.d.acc, cap * sizeof(double4), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d.count, a.d.count, sizeof(int), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    b.g = a.g; b.g_soft = a.g_soft; b.dt = a.dt; b.theta2 = a.theta2;
+    std::memcpy(b.center, a.center, sizeof(b.center));
+    b.width = a.width; b.bnd = a.bnd; b.bounds_set = a.bounds_set;
+    b.elapsed = a.elapsed;
+    b.n_local = a.n_local;
+    return NBODY_OK;   // (like the reference's BH clone, barnes_hut.rs:113-135, the tree is not carried over)
+}
+
+int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
+    State& s = *h->f64;
+    if (stride < 80 || stride % 8) return fail(h, NBODY_ERR_INVALID, "f64 handle: stride must be a multiple of 8 and >= 80 bytes");
+    if (n > size_t(s.d.cap)) return fail(h, NBODY_ERR_CAPACITY, "more bodies than NbodyConfig.capacity");
+    int rc = ensure_aos(h, s, n);
+    if (rc) return rc;
+    const char* src = static_cast<const char*>(aos);
+    for (size_t k = 0; k < n; ++k) std::memcpy(s.h_aos + 10 * k, src + k * stride, 80);
+    if (n) HIP_TRY(h, hipMemcpyAsync(s.d_aos, s.h_aos, n * 80, hipMemcpyHostToDevice, h->stream));
+    launch_aos_to_soa(h->stream, s.d_aos, 10, int(n), s.d, 0);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemsetAsync(s.d.escaped, 0, sizeof(int), h->stream));
+    s.n_local = n;
+    s.count_dirty = false;
+    return push_count(h, s);
+}
+
+int download(NbodyHandle* h, void* aos, size_t cap, size_t stride, size_t* n_out) {
+    State& s = *h->f64;
+    if (stride < 80 || stride % 8) return fail(h, NBODY_ERR_INVALID, "f64 handle: stride must be a multiple of 8 and >= 80 bytes");
+    int rc = sync_count(h, s);
+    if (rc) return rc;
+    const size_t n = s.n_local;
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "download buffer too small");
+    if (n == 0) return NBODY_OK;
+    if (!aos) return fail(h, NBODY_ERR_INVALID, "null buffer");
+    rc = ensure_aos(h, s, n);
+    if (rc) return rc;
+    launch_soa_to_aos(h->stream, s.d_aos, 10, int(n), s.d);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(s.h_aos, s.d_aos, n * 80, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    char* dst = static_cast<char*>(aos);
+    for (size_t k = 0; k < n; ++k) std::memcpy(dst + k * stride, s.h_aos + 10 * k, 80);
+    return NBODY_OK;
+}
+
+int count(NbodyHandle* h, size_t* n_out) {
+    State& s = *h->f64;
+    int rc = sync_count(h, s);
+    if (rc) return rc;
+    *n_out = s.n_local;
+    return NBODY_OK;
+}
+
+int add_point(NbodyHandle* h, const void* particle) {   // Vec::push (brute_force.rs:92-94)
+    State& s = *h->f64;
+    int rc = sync_count(h, s);
+    if (rc) return rc;
+    if (s.n_local >= size_t(s.d.cap)) return fail(h, NBODY_ERR_CAPACITY, "capacity exhausted");
+    rc = ensure_aos(h, s, 1);
+    if (rc) return rc;
+    std::memcpy(s.h_aos, particle, 80);
+    HIP_TRY(h, hipMemcpyAsync(s.d_aos, s.h_aos, 80, hipMemcpyHostToDevice, h->stream));
+    launch_aos_to_soa(h->stream, s.d_aos, 10, 1, s.d, s.n_local);
+    HIP_TRY(h, hipGetLastError());
+    s.n_local += 1;
+    return push_count(h, s);
+}
+
+int remove_point(NbodyHandle* h, size_t index) {   // Vec::swap_remove (brute_force.rs:96-98)
+    State& s = *h->f64;
+    int rc = sync_count(h, s);
+    if (rc) return rc;
+    if (index >= s.n_local) return fail(h, NBODY_ERR_INVALID, "swap_remove index out of range");
+    const size_t last = s.n_local - 1;
+    if (index != last) {
+        HIP_TRY(h, hipMemcpyAsync(s.d.pos + index, s.d.pos + last, sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(s.d.vel + index, s.d.vel + last, sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(s.d.acc + index, s.d.acc + last, sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+    }
+    s.n_local = last;
+    return push_count(h, s);
+}
+
+int set_settings(NbodyHandle* h, double g, double g_soft, double dt, double theta2) {
+    State& s = *h->f64;
+    s.g = g; s.g_soft = g_soft; s.dt = dt; s.theta2 = theta2;
+    return NBODY_OK;
+}
+
+int get_settings(const NbodyHandle* h, double* g, double* g_soft, double* dt, double* theta2) {
+    const State& s = *h->f64;
+    if (g) *g = s.g;
+    if (g_soft) *g_soft = s.g_soft;
+    if (dt) *dt = s.dt;
+    if (theta2) *theta2 = s.theta2;
+    return NBODY_OK;
+}
+
+int set_bounds(NbodyHandle* h, const double center[3], double width) {
+    State& s = *h->f64;
+    std::memcpy(s.center, center, sizeof(s.center));
+    s.width = width;
+    const double hw = width * 0.5;  // Bounds::new
+    for (int i = 0; i < 3; ++i) {
+        s.bnd.lo[i] = center[i] + (-hw);  // add_scalar(-half_width), shared.rs:224
+        s.bnd.hi[i] = center[i] + hw;     // shared.rs:228
+    }
+    s.bounds_set = true;
+    return NBODY_OK;
+}
+
+int init(NbodyHandle* h) {
+    h->f64->elapsed = 0.0;
+    return NBODY_OK;
+}
+
+int step_by(NbodyHandle* h, double dt) { return step_impl(h, *h->f64, dt); }
+
+int steps(NbodyHandle* h, int k) {
+    State& s = *h->f64;
+    for (int i = 0; i < k; ++i) {
+        int rc = step_impl(h, s, s.dt);  // Simulation::step, shared.rs:86-88
+        if (rc) return rc;
+    }
+    return NBODY_OK;
+}
+
+int update_forces(NbodyHandle* h) {
+    State& s = *h->f64;
+    if (h->cfg.method == NBODY_BARNES_HUT && !s.bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+    return forces(h, s);
+}
+
+double elapsed(const NbodyHandle* h) { return h->f64->elapsed; }
+
+int stats(NbodyHandle* h, NbodyStats* out) {
+    State& s = *h->f64;
+    if (h->cfg.method == NBODY_BRUTE_FORCE) {
+        unsigned long long* hv = reinterpret_cast<unsigned long long*>(h->h_poison + 4);   // (pinned scratch)
+        HIP_TRY(h, hipMemcpyAsync(hv, s.d.inter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->stats.interactions = *hv;
+    }
+    if (h->d_counters) {
+        HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        unsigned long long acc_sum = 0, vis_sum = 0;
+        for (unsigned k = 0; k < NBODY_WALK_COUNTER_SLOTS; ++k) { acc_sum += h->h_counters[2 * k]; vis_sum += h->h_counters[2 * k + 1]; }
+        h->stats.interactions = acc_sum;
+        h->stats.force_kernel_interactions = acc_sum;
+        h->stats.node_visits = vis_sum;
+    }
+    *out = h->stats;
+    return NBODY_OK;
+}
+
+int reset_stats(NbodyHandle* h) {
+    State& s = *h->f64;
+    HIP_TRY(h, hipMemsetAsync(s.d.inter, 0, sizeof(unsigned long long), h->stream));
+    return NBODY_OK;
+}
+
+int energy(NbodyHandle* h, double* kinetic, double* potential) {
+    State& s = *h->f64;
+    int rc = sync_count(h, s);
+    if (rc) return rc;
+    const size_t n = s.n_local;
+    const size_t blocks = (n + 255) / 256;
+    double ke = 0.0, pe = 0.0;
+    if (blocks) {
+        if (blocks > s.energy_blocks) {
+            if (s.d_energy) (void)hipFree(s.d_energy);
+            s.d_energy = nullptr; s.energy_blocks = 0;
+            HIP_TRY(h, hipMalloc(&s.d_energy, blocks * 2 * sizeof(double)));
+            s.energy_blocks = blocks;
+        }
+        launch_energy(h->stream, s.d, int(n), s.g_soft * s.g_soft, s.d_energy);
+        HIP_TRY(h, hipGetLastError());
+        std::vector<double> part(blocks * 2);
+        HIP_TRY(h, hipMemcpyAsync(part.data(), s.d_energy, blocks * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (size_t b = 0; b < blocks; ++b) { ke += part[2 * b]; pe += part[2 * b + 1]; }
+    }
+    if (kinetic) *kinetic = ke;
+    if (potential) *potential = -0.5 * s.g * pe;  // every unordered pair was met twice
+    return NBODY_OK;
+}
+
+int tree_export(NbodyHandle* h, double* com_mass, double* width, int32_t* skip, size_t cap, size_t* n_nodes) {
+    State& s = *h->f64;
+    const size_t n = s.tree.n_nodes;
+    if (n_nodes) *n_nodes = n;
+    if (!com_mass && !width && !skip) return NBODY_OK;
+    if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "tree export buffer too small");
+    for (size_t i = 0; i < n; ++i) {
+        const nbody::NodeRecT<double>& r = s.tree.nodes[i];
+        if (com_mass) { com_mass[4 * i] = r.a.x; com_mass[4 * i + 1] = r.a.y; com_mass[4 * i + 2] = r.a.z; com_mass[4 * i + 3] = r.a.m; }
+        if (width) width[i] = std::sqrt(r.b.w2);  // exact: w2 is the rounded square of the width
+        if (skip) skip[i] = r.b.skip;
+    }
+    return NBODY_OK;
+}
+
+}  // namespace nbody64

@@ -188,7 +188,8 @@ void WorkerPool::run(int n_tasks, const std::function<void(int)>& fn) {
 }
 
 // ------------------------------------------------------------------------------ output arrays
-void HostTree::clear() {
+template <class T>
+void HostTreeT<T>::clear() {
     auto rel = release ? release : +[](void* p) { std::free(p); };
     if (nodes) rel(nodes);
     if (order) rel(order);
@@ -196,13 +197,14 @@ void HostTree::clear() {
     cap_nodes = cap_order = n_nodes = n_order = 0;
 }
 
-void HostTree::reserve(size_t n_nodes_wanted, size_t order_n) {
+template <class T>
+void HostTreeT<T>::reserve(size_t n_nodes_wanted, size_t order_n) {
     auto al = alloc ? alloc : +[](size_t n) { return std::malloc(n); };
     auto rel = release ? release : +[](void* p) { std::free(p); };
     if (n_nodes_wanted > cap_nodes) {
         size_t cap = n_nodes_wanted + n_nodes_wanted / 4 + 64;
         if (nodes) rel(nodes);
-        nodes = static_cast<NodeRec*>(al(cap * sizeof(NodeRec)));
+        nodes = static_cast<NodeRecT<T>*>(al(cap * sizeof(NodeRecT<T>)));
         cap_nodes = cap;
     }
     if (order_n > cap_order) {
@@ -216,34 +218,37 @@ void HostTree::reserve(size_t n_nodes_wanted, size_t order_n) {
 // --------------------------------------------------------------------------------- the build
 namespace {
 
-struct Item { float x, y, z, m; int32_t id; };
+template <class T> struct ItemT { T x, y, z, m; int32_t id; };
 
-struct Box {
-    float c[3];
-    float hw, w;
-    Box child(int o) const {  // Bounds::create_orthant
-        Box b;
-        b.w = w * 0.5f;
-        b.hw = hw * 0.5f;
+template <class T>
+struct BoxT {
+    T c[3];
+    T hw, w;
+    BoxT child(int o) const {  // Bounds::create_orthant
+        BoxT b;
+        b.w = w * T(0.5);
+        b.hw = hw * T(0.5);
         for (int i = 0; i < 3; ++i) b.c[i] = (o >> i & 1) ? c[i] + b.hw : c[i] - b.hw;
         return b;
     }
 };
 
-struct Emit {
-    std::vector<NodeRec> nodes;
+template <class T>
+struct EmitT {
+    std::vector<NodeRecT<T>> nodes;
     std::vector<int32_t> order;
     bool too_deep = false;
     int max_depth = 0;
 };
 
 // classify + fold; returns per-orthant counts in cnt[8], the node's mass and com
-inline void classify_and_sum(const Item* src, uint8_t* code, int n, const Box& box, int cnt[8], NodeA& node) {
+template <class T>
+inline void classify_and_sum(const ItemT<T>* src, uint8_t* code, int n, const BoxT<T>& box, int cnt[8], NodeAT<T>& node) {
     for (int o = 0; o < 8; ++o) cnt[o] = 0;
-    float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-    const float cx = box.c[0], cy = box.c[1], cz = box.c[2];
+    T mass = 0, sx = 0, sy = 0, sz = 0;
+    const T cx = box.c[0], cy = box.c[1], cz = box.c[2];
     for (int k = 0; k < n; ++k) {
-        const Item& it = src[k];
+        const ItemT<T>& it = src[k];
         int o = (it.x > cx ? 1 : 0) | (it.y > cy ? 2 : 0) | (it.z > cz ? 4 : 0);
         code[k] = uint8_t(o);
         cnt[o]++;
@@ -258,7 +263,8 @@ inline void classify_and_sum(const Item* src, uint8_t* code, int n, const Box& b
     node.z = sz / mass;
 }
 
-inline void scatter(const Item* src, Item* dst, const uint8_t* code, int n, const int cnt[8], int start[8]) {
+template <class T>
+inline void scatter(const ItemT<T>* src, ItemT<T>* dst, const uint8_t* code, int n, const int cnt[8], int start[8]) {
     int off[8];
     int run = 0;
     for (int o = 0; o < 8; ++o) { start[o] = off[o] = run; run += cnt[o]; }
@@ -266,20 +272,21 @@ inline void scatter(const Item* src, Item* dst, const uint8_t* code, int n, cons
 }
 
 // pn, gpn: bodies in the parent and grandparent cells (NodeB::hot)
-void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int depth, Emit& e, int pn, int gpn) {
+template <class T>
+void build_rec(ItemT<T>* src, ItemT<T>* tmp, uint8_t* code, int n, const BoxT<T>& box, int depth, EmitT<T>& e, int pn, int gpn) {
     const int me = int(e.nodes.size());
     if (depth > e.max_depth) e.max_depth = depth;
-    e.nodes.push_back(NodeRec{NodeA{0.f, 0.f, 0.f, 0.f}, NodeB{box.w * box.w, me + 1, gpn, -1}});
+    e.nodes.push_back(NodeRecT<T>{NodeAT<T>{0, 0, 0, 0}, NodeBT<T>{box.w * box.w, me + 1, gpn, -1}});
     if (n == 0) return;
     if (n == 1) {
-        e.nodes[me].a = NodeA{src[0].x, src[0].y, src[0].z, src[0].m};
+        e.nodes[me].a = NodeAT<T>{src[0].x, src[0].y, src[0].z, src[0].m};
         e.nodes[me].b.body = src[0].id;
         e.order.push_back(src[0].id);
         return;
     }
     if (depth >= NBODY_MAX_TREE_DEPTH) { e.too_deep = true; return; }
     int cnt[8], start[8];
-    NodeA node;
+    NodeAT<T> node;
     classify_and_sum(src, code, n, box, cnt, node);
     scatter(src, tmp, code, n, cnt, start);
     for (int o = 0; o < 8; ++o)
@@ -290,23 +297,27 @@ void build_rec(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
 
 constexpr int kTaskDepth = 2;
 
-struct Task { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; Emit* out; int pn, gpn; };
+template <class T> struct TaskT { ItemT<T>* src; ItemT<T>* tmp; uint8_t* code; int n; BoxT<T> box; int depth; EmitT<T>* out; int pn, gpn; };
 
-struct TopEntry {
+template <class T>
+struct TopEntryT {
     int task = -1;   // >= 0: the subtree built by that task; else a node of the top levels
-    NodeA a{};
-    NodeB b{};
+    NodeAT<T> a{};
+    NodeBT<T> b{};
     int end = 0;     // node entries: index of the first entry after this node's subtree
+    int depth = 0;
 };
 
-void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int depth, std::vector<TopEntry>& top,
-               std::vector<Task>& tasks, int pn, int gpn) {
+template <class T>
+void build_top(ItemT<T>* src, ItemT<T>* tmp, uint8_t* code, int n, const BoxT<T>& box, int depth, std::vector<TopEntryT<T>>& top,
+               std::vector<TaskT<T>>& tasks, int pn, int gpn) {
     const int me = int(top.size());
     top.emplace_back();
-    top[me].b = NodeB{box.w * box.w, 0, gpn, -1};
+    top[me].b = NodeBT<T>{box.w * box.w, 0, gpn, -1};
+    top[me].depth = depth;
     if (n == 0) { top[me].end = me + 1; return; }
     if (n == 1) {
-        top[me].a = NodeA{src[0].x, src[0].y, src[0].z, src[0].m};
+        top[me].a = NodeAT<T>{src[0].x, src[0].y, src[0].z, src[0].m};
         top[me].b.body = src[0].id;
         top[me].end = me + 1;
         return;
@@ -314,11 +325,11 @@ void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
     if (depth >= kTaskDepth) {
         top[me].task = int(tasks.size());
         top[me].end = me + 1;
-        tasks.push_back(Task{src, tmp, code, n, box, depth, nullptr, pn, gpn});
+        tasks.push_back(TaskT<T>{src, tmp, code, n, box, depth, nullptr, pn, gpn});
         return;
     }
     int cnt[8], start[8];
-    NodeA node;
+    NodeAT<T> node;
     classify_and_sum(src, code, n, box, cnt, node);
     scatter(src, tmp, code, n, cnt, start);
     for (int o = 0; o < 8; ++o)
@@ -329,16 +340,26 @@ void build_top(Item* src, Item* tmp, uint8_t* code, int n, const Box& box, int d
 
 }  // namespace
 
-struct BuildScratch::Impl {
-    std::vector<Item> buf_a, buf_b;
+template <class T>
+struct BuildScratchT<T>::Impl {
+    std::vector<ItemT<T>> buf_a, buf_b;
     std::vector<uint8_t> code;
-    std::vector<Emit> emits;  // one per subtree task; capacities survive from step to step
+    std::vector<EmitT<T>> emits;  // one per subtree task; capacities survive from step to step
 };
-BuildScratch::BuildScratch() : impl(new Impl) {}
-BuildScratch::~BuildScratch() { delete impl; }
+template <class T> BuildScratchT<T>::BuildScratchT() : impl(new Impl) {}
+template <class T> BuildScratchT<T>::~BuildScratchT() { delete impl; }
 
-void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, const float center[3], float width,
-                  WorkerPool& pool, BuildScratch& scratch, HostTree& out) {
+template <class T>
+void build_octree(const T* pos4, int n_seg, int seg_cap, const int* count, const T center[3], T width,
+                  WorkerPool& pool, BuildScratchT<T>& scratch, HostTreeT<T>& out) {
+    using Item = ItemT<T>;
+    using Box = BoxT<T>;
+    using Emit = EmitT<T>;
+    using Task = TaskT<T>;
+    using TopEntry = TopEntryT<T>;
+    using NodeA = NodeAT<T>;
+    using NodeB = NodeBT<T>;
+    using NodeRec = NodeRecT<T>;
     size_t n = 0;
     std::vector<size_t> seg_first(n_seg + 1, 0);
     for (int s = 0; s < n_seg; ++s) { seg_first[s] = n; n += size_t(count[s]); }
@@ -356,10 +377,10 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
 
     Box root;
     root.c[0] = center[0]; root.c[1] = center[1]; root.c[2] = center[2];
-    root.hw = width * 0.5f;  // Bounds::new, shared.rs:236-243
+    root.hw = width * T(0.5);  // Bounds::new, shared.rs:236-243
     root.w = width;
 
-    const int T = pool.size();
+    const int n_thr = pool.size();
     static const bool timing = std::getenv("NBODY_TREE_TIMING") != nullptr;
     auto t_start = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -374,14 +395,14 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         for (size_t k = k0; k < k1; ++k) {
             while (k >= seg_first[s + 1]) ++s;
             const size_t j = k - seg_first[s];
-            const float* p = pos4 + 4 * (size_t(s) * seg_cap + j);
+            const T* p = pos4 + 4 * (size_t(s) * seg_cap + j);
             A[k] = Item{p[0], p[1], p[2], p[3], int32_t(size_t(s) * seg_cap + j)};
         }
     };
 
     std::vector<TopEntry> top;
     std::vector<Task> tasks;
-    if (n < 8192 || T == 1) {
+    if (n < 8192 || n_thr == 1) {
         fill(0, n);
         build_top(A, B, C, int(n), root, 0, top, tasks, int(n), int(n));
     } else {
@@ -391,9 +412,9 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         // Depth alone is a poor cut: a Plummer sphere in a wide box keeps most bodies in 8 cells
         // per level for several levels.
         struct Big { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; int self; int pn; };  // pn: bodies in the parent cell
-        struct TNode { NodeA a{}; NodeB b{}; int child[8]; int task = -1; };
+        struct TNode { NodeA a{}; NodeB b{}; int child[8]; int task = -1; int depth = 0; };
         std::vector<TNode> tn;
-        auto new_tnode = [&](const Box& bx, int hot) { TNode t; t.b = NodeB{bx.w * bx.w, 0, hot, -1}; for (int& c : t.child) c = -1; tn.push_back(t); return int(tn.size()) - 1; };
+        auto new_tnode = [&](const Box& bx, int hot, int depth) { TNode t; t.b = NodeB{bx.w * bx.w, 0, hot, -1}; t.depth = depth; for (int& c : t.child) c = -1; tn.push_back(t); return int(tn.size()) - 1; };
         const int big = std::max(2048, int(n / 64));
         const int chunk = std::max(1024, big / 2);
         // the root's fold is a 4 x n-long dependent chain (~50 us at n = 65 536) nobody needs before the
@@ -401,17 +422,17 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
         // id order = the order fill() puts the bodies in)
         NodeA root_fold{};
         const std::function<void()> fold_root = [&] {
-            float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+            T mass = 0, sx = 0, sy = 0, sz = 0;
             for (int sg = 0; sg < n_seg; ++sg) {
-                const float* p = pos4 + 4 * (size_t(sg) * seg_cap);
+                const T* p = pos4 + 4 * (size_t(sg) * seg_cap);
                 for (int j = 0; j < count[sg]; ++j, p += 4) { mass += p[3]; sx += p[0] * p[3]; sy += p[1] * p[3]; sz += p[2] * p[3]; }
             }
             root_fold = NodeA{sx / mass, sy / mass, sz / mass, mass};
         };
         pool.post_background(fold_root);
-        pool.run(T, [&](int t) { const size_t c = (n + T - 1) / T; fill(std::min(n, size_t(t) * c), std::min(n, size_t(t + 1) * c)); });
+        pool.run(n_thr, [&](int t) { const size_t c = (n + n_thr - 1) / n_thr; fill(std::min(n, size_t(t) * c), std::min(n, size_t(t + 1) * c)); });
         lap("fill");
-        std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root, int(n)), int(n)}};
+        std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root, int(n), 0), int(n)}};
         struct Piece { int node; int k0, k1; };
         while (!level.empty()) {
             std::vector<Piece> pieces;
@@ -423,7 +444,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
                 if (t < NB) {  // the node's fold (handed out first: they are the long tasks of the run)
                     const Big& g = level[t];
                     if (g.depth == 0) return;  // the root's runs in the background
-                    float mass = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+                    T mass = 0, sx = 0, sy = 0, sz = 0;
                     for (int k = 0; k < g.n; ++k) { const Item& it = g.src[k]; mass += it.m; sx += it.x * it.m; sy += it.y * it.m; sz += it.z * it.m; }
                     tn[g.self].a = NodeA{sx / mass, sy / mass, sz / mass, mass};
                     return;
@@ -460,7 +481,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
                     const int cn = ntot[b][o];
                     if (!cn) continue;
                     const Box cb = g.box.child(o);
-                    const int id = new_tnode(cb, g.pn);  // the child's grandparent is g's parent
+                    const int id = new_tnode(cb, g.pn, g.depth + 1);  // the child's grandparent is g's parent
                     tn[g.self].child[o] = id;
                     Item* csrc = g.tmp + nstart[b][o];
                     Item* ctmp = g.src + nstart[b][o];
@@ -490,6 +511,7 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
             top[me].a = tn[id].a;
             top[me].b = tn[id].b;
             top[me].task = tn[id].task;
+            top[me].depth = tn[id].depth;
             for (int o = 0; o < 8; ++o) if (tn[id].child[o] >= 0) emit(tn[id].child[o]);
             top[me].end = int(top.size());
         };
@@ -546,17 +568,15 @@ void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, c
     });
     out.max_depth = 0;
     for (auto& tk : tasks) { out.too_deep = out.too_deep || tk.out->too_deep; out.max_depth = std::max(out.max_depth, tk.out->max_depth); }
-    {   // nodes above the subtree tasks: depth from the width, which halves exactly per level
-        int32_t b0, bi;
-        const float w2_root = root.w * root.w;
-        std::memcpy(&b0, &w2_root, 4);
-        for (const TopEntry& te : top) {
-            if (te.task >= 0) continue;
-            std::memcpy(&bi, &te.b.w2, 4);
-            out.max_depth = std::max(out.max_depth, int((b0 - bi) >> 24));
-        }
-    }
+    for (const TopEntry& te : top) if (te.task < 0) out.max_depth = std::max(out.max_depth, te.depth);   // nodes above the subtree tasks
     lap("splice");
 }
+
+template struct HostTreeT<float>;
+template struct HostTreeT<double>;
+template struct BuildScratchT<float>;
+template struct BuildScratchT<double>;
+template void build_octree<float>(const float*, int, int, const int*, const float[3], float, WorkerPool&, BuildScratchT<float>&, HostTreeT<float>&);
+template void build_octree<double>(const double*, int, int, const int*, const double[3], double, WorkerPool&, BuildScratchT<double>&, HostTreeT<double>&);
 
 }  // namespace nbody

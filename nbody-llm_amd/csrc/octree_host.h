@@ -44,20 +44,27 @@ private:
     int sleepers_ = 0;                  // under m_
 };
 
-struct NodeA { float x, y, z, m; };               // centre of mass, mass
+// One record per node, templated on the reference's F (f32 or f64; shared.rs:12-44): a single 32-byte (f32) or
+// 64-byte (f64) load on the device.
+template <class T> struct NodeAT { T x, y, z, m; };   // centre of mass, mass
 // width^2, skip, "hot" = bodies in the node's GRANDPARENT cell (the root's count for depths 0 and 1), body id of
 // a leaf or -1.  The width itself is sqrt(w2), exactly (IEEE sqrt of a rounded square returns the operand).
 // hot ranks the nodes by how many walks visit them (a node is visited by the bodies that open its parent,
 // i.e. those within parent-width / theta of it: about the population around the grandparent cell); the
-// fast walk stages the highest-ranked records in LDS (kernels_bh.hip).  tools/bh_visit_hist.py: the 2 048
-// nodes ranked first by this score take 66 % of all visits at N = 65 536, the 2 048 truly hottest 67 %.
-struct NodeB { float w2; int32_t skip; int32_t hot; int32_t body; };
-struct alignas(32) NodeRec { NodeA a; NodeB b; };  // one 32-byte record per node: a single s_load_dwordx8 on the device
+// LDS-staged walk keeps the highest-ranked records in LDS (kernels_bh.hip, variant 3).  tools/bh_visit_hist.py: the
+// 2 048 nodes ranked first by this score take 66 % of all visits at N = 65 536, the 2 048 truly hottest 67 %.
+template <class T> struct NodeBT { T w2; int32_t skip; int32_t hot; int32_t body; };
+template <class T> struct alignas(sizeof(T) * 8) NodeRecT { NodeAT<T> a; NodeBT<T> b; };
+using NodeA = NodeAT<float>;
+using NodeB = NodeBT<float>;
+using NodeRec = NodeRecT<float>;
+static_assert(sizeof(NodeRecT<float>) == 32 && sizeof(NodeRecT<double>) == 64, "node record layout");
 
 // Output arrays live in caller-chosen memory (the API hands in pinned-host allocators so the
 // H2D copy of the node array is a single DMA; tests use malloc).
-struct HostTree {
-    NodeRec* nodes = nullptr;
+template <class T>
+struct HostTreeT {
+    NodeRecT<T>* nodes = nullptr;
     int32_t* order = nullptr;  // body ids in depth-first leaf order
     size_t n_nodes = 0, n_order = 0;
     size_t cap_nodes = 0, cap_order = 0;
@@ -67,26 +74,30 @@ struct HostTree {
     void (*release)(void*) = nullptr;
     void reserve(size_t n_nodes_wanted, size_t order_n);
     void clear();
-    ~HostTree() { clear(); }
-    HostTree() = default;
-    HostTree(const HostTree&) = delete;
-    HostTree& operator=(const HostTree&) = delete;
+    ~HostTreeT() { clear(); }
+    HostTreeT() = default;
+    HostTreeT(const HostTreeT&) = delete;
+    HostTreeT& operator=(const HostTreeT&) = delete;
 };
+using HostTree = HostTreeT<float>;
 
 // pos4: {x,y,z,m} records; the bodies are the concatenation of n_seg segments of seg_cap slots
 // holding count[s] live bodies each; a body's id is s*seg_cap + j.  Bodies enter the build in id
 // order, which is the reference's vector order.
 // working memory of the build, kept from step to step
-struct BuildScratch {
+template <class T>
+struct BuildScratchT {
     struct Impl;
     Impl* impl;
-    BuildScratch();
-    ~BuildScratch();
-    BuildScratch(const BuildScratch&) = delete;
-    BuildScratch& operator=(const BuildScratch&) = delete;
+    BuildScratchT();
+    ~BuildScratchT();
+    BuildScratchT(const BuildScratchT&) = delete;
+    BuildScratchT& operator=(const BuildScratchT&) = delete;
 };
+using BuildScratch = BuildScratchT<float>;
 
-void build_octree(const float* pos4, int n_seg, int seg_cap, const int* count, const float center[3], float width,
-                  WorkerPool& pool, BuildScratch& scratch, HostTree& out);
+template <class T>
+void build_octree(const T* pos4, int n_seg, int seg_cap, const int* count, const T center[3], T width,
+                  WorkerPool& pool, BuildScratchT<T>& scratch, HostTreeT<T>& out);
 
 }  // namespace nbody

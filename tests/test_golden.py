@@ -50,14 +50,18 @@ def test_f32_golden_tracks_f64_golden(stem):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", [p for p in GOLDEN if "_f32_" in p], ids=os.path.basename)
-def test_hip_path_reproduces_golden(gpu, path):
+@pytest.mark.parametrize("path", GOLDEN, ids=os.path.basename)
+def test_hip_path_reproduces_golden(gpu, orc, path):
+    """f32 AND f64 fixtures: an f64 fixture runs on an NBODY_F64 handle (80-byte records, f64 settings)."""
     nb = gpu
     z, st, center, width = load(path)
     kind = str(z["kind"])
+    f64 = str(z["ftype"]) == "f64"
     method = nb.BRUTE_FORCE if kind == "bf" else nb.BARNES_HUT
-    with nb.Simulation(z["ics"], center, width, method=method, math_mode=nb.STRICT,
+    ics = orc.to_f64(z["ics"]).astype(nb.PARTICLE_DTYPE64) if f64 else z["ics"]
+    with nb.Simulation(ics, center, width, method=method, math_mode=nb.STRICT,
                        leaf_mode=nb.LEAF_DIRECT if kind == "bhd" else nb.LEAF_REFERENCE) as sim:
+        assert sim.f64 == f64
         sim.settings = nb.Settings(**st)
         sim.init()
         sim.steps(int(z["steps"]))
@@ -68,5 +72,7 @@ def test_hip_path_reproduces_golden(gpu, path):
         assert s.interactions == int(z["counts"][:, 0].sum()) and s.node_visits == int(z["counts"][:, 1].sum())
     # strict math reproduces the oracle's rounding sequence on every path: brute force (ascending partner
     # order), Barnes-Hut with the reference's nested sums, and the src/llm leaf rule's single running sum
+    bits = np.uint64 if f64 else np.uint32
     for f in ("position", "velocity", "acceleration", "mass"):
-        assert np.array_equal(got[f].view(np.uint32), z[f].view(np.uint32)), f
+        assert got[f].dtype == z[f].dtype
+        assert np.array_equal(got[f].view(bits), z[f].view(bits)), f
