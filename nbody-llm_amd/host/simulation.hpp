@@ -3,7 +3,8 @@
 // toolchain, so the host side above the ABI is restated in C++ with the trait's method names,
 // argument meaning and ownership rules (the Rust shim itself is nbody-llm_amd/rust/, untested).
 //
-//   nbody::PointParticle          = shared.rs:151-158 (#[repr(C)], 40 bytes)
+//   nbody::PointParticleT<F>      = shared.rs:151-158 (#[repr(C)]; F = float: 40 bytes, F = double: 80 bytes --
+//                                   the reference's trait is generic over Float and its driver runs f64)
 //   nbody::SimulationSettings     = shared.rs:61-78
 //   nbody::Bounds                 = shared.rs:216-243 (center, width)
 //   nbody::Simulation             = shared.rs:80-97   (abstract)
@@ -28,66 +29,87 @@
 
 namespace nbody {
 
-struct PointParticle {  // PointParticle<f32, 3>
-    float position[3];
-    float velocity[3];
-    float acceleration[3];
-    float mass;
+template <class F>
+struct PointParticleT {  // PointParticle<F, 3>
+    F position[3];
+    F velocity[3];
+    F acceleration[3];
+    F mass;
 };
-static_assert(sizeof(PointParticle) == 40, "PointParticle must match the reference's #[repr(C)] layout");
+using PointParticle = PointParticleT<float>;
+using PointParticle64 = PointParticleT<double>;
+static_assert(sizeof(PointParticle) == 40 && sizeof(PointParticle64) == 80, "PointParticle must match the reference's #[repr(C)] layout");
 
-struct SimulationSettings {  // defaults: shared.rs:69-78
-    float g = 1.0f;
-    float g_soft = 0.0f;
-    float dt = 1e-3f;
-    float theta2 = 0.5f;
+template <class F>
+struct SimulationSettingsT {  // defaults: shared.rs:69-78
+    F g = F(1.0);
+    F g_soft = F(0.0);
+    F dt = F(1e-3);
+    F theta2 = F(0.5);
 };
+using SimulationSettings = SimulationSettingsT<float>;
 
-struct Bounds {  // Bounds::new(center, width)
-    std::array<float, 3> center{0.f, 0.f, 0.f};
-    float width = 1.f;
+template <class F>
+struct BoundsT {  // Bounds::new(center, width)
+    std::array<F, 3> center{F(0), F(0), F(0)};
+    F width = F(1);
 };
+using Bounds = BoundsT<float>;
 
 struct Error : std::runtime_error {
     int code;
     Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
 };
 
-class Simulation {
+namespace abi {  // the f32 / f64 forms of the entry points that carry scalars
+inline int set_settings(NbodyHandle* h, float g, float e, float dt, float t2) { return nbody_set_settings(h, g, e, dt, t2); }
+inline int set_settings(NbodyHandle* h, double g, double e, double dt, double t2) { return nbody_set_settings_f64(h, g, e, dt, t2); }
+inline int set_bounds(NbodyHandle* h, const float* c, float w) { return nbody_set_bounds(h, c, w); }
+inline int set_bounds(NbodyHandle* h, const double* c, double w) { return nbody_set_bounds_f64(h, c, w); }
+inline int step_by(NbodyHandle* h, float dt) { return nbody_step_by(h, dt); }
+inline int step_by(NbodyHandle* h, double dt) { return nbody_step_by_f64(h, dt); }
+inline int elapsed(const NbodyHandle* h, float* t) { return nbody_elapsed(h, t); }
+inline int elapsed(const NbodyHandle* h, double* t) { return nbody_elapsed_f64(h, t); }
+template <class F> constexpr int dtype_of() { return sizeof(F) == 8 ? NBODY_F64 : NBODY_F32; }
+}  // namespace abi
+
+template <class F>
+class SimulationT {
 public:
-    virtual ~Simulation() { if (h_) nbody_destroy(h_); }
-    Simulation(const Simulation&) = delete;
-    Simulation& operator=(const Simulation&) = delete;
+    using Particle = PointParticleT<F>;
+    virtual ~SimulationT() { if (h_) nbody_destroy(h_); }
+    SimulationT(const SimulationT&) = delete;
+    SimulationT& operator=(const SimulationT&) = delete;
 
     void init() { check(nbody_init(h_)); }                                  // shared.rs:85
     void step() { push_settings(); check(nbody_steps(h_, 1)); dirty_ = true; }   // :86-88
     void steps(int k) { push_settings(); check(nbody_steps(h_, k)); dirty_ = true; }  // k x step(), no host sync
-    void step_by(float dt) { push_settings(); check(nbody_step_by(h_, dt)); dirty_ = true; }  // :89
+    void step_by(F dt) { push_settings(); check(abi::step_by(h_, dt)); dirty_ = true; }  // :89
     void update_forces() { push_settings(); check(nbody_update_forces(h_)); dirty_ = true; }  // :90
-    void add_point(const PointParticle& p) { check(nbody_add_point(h_, &p)); dirty_ = true; }  // :91
+    void add_point(const Particle& p) { check(nbody_add_point(h_, &p)); dirty_ = true; }  // :91
     void remove_point(size_t index) { check(nbody_remove_point(h_, index)); dirty_ = true; }   // :92 (swap_remove)
-    const std::vector<PointParticle>& get_points() const {                  // :93
+    const std::vector<Particle>& get_points() const {                       // :93
         if (dirty_) {
             size_t n = 0;
             check(nbody_count(h_, &n));
             points_.resize(n);
-            check(nbody_download(h_, points_.data(), n, sizeof(PointParticle), &n));
+            check(nbody_download(h_, points_.data(), n, sizeof(Particle), &n));
             points_.resize(n);
             dirty_ = false;
         }
         return points_;
     }
-    float elapsed() const { float t = 0; check(nbody_elapsed(h_, &t)); return t; }   // :94
-    const SimulationSettings& settings() const { return settings_; }        // :95
-    SimulationSettings& settings_mut() { settings_dirty_ = true; return settings_; }  // :96
+    F elapsed() const { F t = 0; check(abi::elapsed(h_, &t)); return t; }   // :94
+    const SimulationSettingsT<F>& settings() const { return settings_; }    // :95
+    SimulationSettingsT<F>& settings_mut() { settings_dirty_ = true; return settings_; }  // :96
     void sync() { check(nbody_sync(h_)); }
     NbodyStats stats() { NbodyStats s{}; check(nbody_stats(h_, &s)); return s; }
     NbodyHandle* handle() { return h_; }
 
 protected:
-    Simulation(int method, const std::vector<PointParticle>& points, const Bounds& bounds, int math_mode,
-               size_t capacity, int host_threads, int tree_build = NBODY_TREE_AUTO,
-               int leaf_mode = NBODY_LEAF_REFERENCE) : bounds_(bounds) {
+    SimulationT(int method, const std::vector<Particle>& points, const BoundsT<F>& bounds, int math_mode,
+                size_t capacity, int host_threads, int tree_build = NBODY_TREE_AUTO,
+                int leaf_mode = NBODY_LEAF_REFERENCE) : bounds_(bounds) {
         NbodyConfig cfg{};
         cfg.struct_size = sizeof(cfg);
         cfg.method = method;
@@ -99,12 +121,13 @@ protected:
         cfg.host_threads = host_threads;
         cfg.capacity = capacity ? capacity : (points.empty() ? 1 : points.size());
         cfg.tree_build = tree_build;
+        cfg.dtype = abi::dtype_of<F>();
         int rc = nbody_create(&cfg, &h_);
         if (rc) throw Error(rc, nbody_last_error(nullptr));
-        check(nbody_set_bounds(h_, bounds.center.data(), bounds.width));
-        check(nbody_upload(h_, points.data(), points.size(), sizeof(PointParticle)));
+        check(abi::set_bounds(h_, bounds.center.data(), bounds.width));
+        check(nbody_upload(h_, points.data(), points.size(), sizeof(Particle)));
     }
-    explicit Simulation(NbodyHandle* cloned, const Simulation& src)
+    explicit SimulationT(NbodyHandle* cloned, const SimulationT& src)
         : h_(cloned), settings_(src.settings_), bounds_(src.bounds_) {}
     NbodyHandle* clone_handle() const {                                     // `Clone` supertrait
         NbodyHandle* c = nullptr;
@@ -115,42 +138,47 @@ protected:
     void check(int rc) const { if (rc) throw Error(rc, nbody_last_error(h_)); }
     void push_settings() {
         if (!settings_dirty_) return;
-        check(nbody_set_settings(h_, settings_.g, settings_.g_soft, settings_.dt, settings_.theta2));
+        check(abi::set_settings(h_, settings_.g, settings_.g_soft, settings_.dt, settings_.theta2));
         settings_dirty_ = false;
     }
 
     NbodyHandle* h_ = nullptr;
-    SimulationSettings settings_{};
-    Bounds bounds_{};
+    SimulationSettingsT<F> settings_{};
+    BoundsT<F> bounds_{};
     bool settings_dirty_ = true;
     mutable bool dirty_ = true;
-    mutable std::vector<PointParticle> points_;
+    mutable std::vector<Particle> points_;
 };
+using Simulation = SimulationT<float>;
 
 // Simulation::new(points, LeapFrogIntegrator::new(), bounds) for the two solvers of src/manual
-class BruteForceSimulation : public Simulation {
+template <class F>
+class BruteForceSimulationT : public SimulationT<F> {
 public:
-    BruteForceSimulation(const std::vector<PointParticle>& points, const Bounds& bounds,
-                         int math_mode = NBODY_MATH_FAST, size_t capacity = 0)
-        : Simulation(NBODY_BRUTE_FORCE, points, bounds, math_mode, capacity, 0) {}
-    std::unique_ptr<BruteForceSimulation> clone() const {
-        return std::unique_ptr<BruteForceSimulation>(new BruteForceSimulation(clone_handle(), *this));
+    BruteForceSimulationT(const std::vector<PointParticleT<F>>& points, const BoundsT<F>& bounds,
+                          int math_mode = NBODY_MATH_FAST, size_t capacity = 0)
+        : SimulationT<F>(NBODY_BRUTE_FORCE, points, bounds, math_mode, capacity, 0) {}
+    std::unique_ptr<BruteForceSimulationT> clone() const {
+        return std::unique_ptr<BruteForceSimulationT>(new BruteForceSimulationT(this->clone_handle(), *this));
     }
 private:
-    BruteForceSimulation(NbodyHandle* h, const Simulation& src) : Simulation(h, src) {}
+    BruteForceSimulationT(NbodyHandle* h, const SimulationT<F>& src) : SimulationT<F>(h, src) {}
 };
+using BruteForceSimulation = BruteForceSimulationT<float>;
 
-class BarnesHutSimulation : public Simulation {
+template <class F>
+class BarnesHutSimulationT : public SimulationT<F> {
 public:
-    BarnesHutSimulation(const std::vector<PointParticle>& points, const Bounds& bounds,
-                        int math_mode = NBODY_MATH_FAST, size_t capacity = 0, int host_threads = 0,
-                        int tree_build = NBODY_TREE_AUTO, int leaf_mode = NBODY_LEAF_REFERENCE)
-        : Simulation(NBODY_BARNES_HUT, points, bounds, math_mode, capacity, host_threads, tree_build, leaf_mode) {}
-    std::unique_ptr<BarnesHutSimulation> clone() const {
-        return std::unique_ptr<BarnesHutSimulation>(new BarnesHutSimulation(clone_handle(), *this));
+    BarnesHutSimulationT(const std::vector<PointParticleT<F>>& points, const BoundsT<F>& bounds,
+                         int math_mode = NBODY_MATH_FAST, size_t capacity = 0, int host_threads = 0,
+                         int tree_build = NBODY_TREE_AUTO, int leaf_mode = NBODY_LEAF_REFERENCE)
+        : SimulationT<F>(NBODY_BARNES_HUT, points, bounds, math_mode, capacity, host_threads, tree_build, leaf_mode) {}
+    std::unique_ptr<BarnesHutSimulationT> clone() const {
+        return std::unique_ptr<BarnesHutSimulationT>(new BarnesHutSimulationT(this->clone_handle(), *this));
     }
 private:
-    BarnesHutSimulation(NbodyHandle* h, const Simulation& src) : Simulation(h, src) {}
+    BarnesHutSimulationT(NbodyHandle* h, const SimulationT<F>& src) : SimulationT<F>(h, src) {}
 };
+using BarnesHutSimulation = BarnesHutSimulationT<float>;
 
 }  // namespace nbody

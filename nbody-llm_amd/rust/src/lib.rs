@@ -1,19 +1,28 @@
-//! `HipBruteForceSimulation` / `HipBarnesHutSimulation`: the reference's `Simulation` trait
-//! (src/shared.rs:80-97) implemented over include/nbody_hip.h.
+//! `HipBruteForceSimulation<F>` / `HipBarnesHutSimulation<F>`: the reference's `Simulation` trait
+//! (src/shared.rs:80-97) and its `Renderable` trait (src/render/mod.rs:12-15) implemented over
+//! include/nbody_hip.h, for F = f32 and F = f64 (the reference's driver runs f64, src/main.rs:52-105).
 //!
-//! UNTESTED SOURCE: there is no Rust toolchain in the build image.  The C-ABI side of every call
-//! below is covered by tests/ through the ctypes binding and the C++ mirror
-//! (nbody-llm_amd/host/simulation.hpp), which use the same entry points in the same order.
+//! UNCOMPILED SOURCE: there is no Rust toolchain in the build image (and the reference needs nightly plus
+//! network access to build).  The C-ABI side of every call below is covered by tests/ through the ctypes
+//! binding and the C++ mirror (nbody-llm_amd/host/simulation.hpp), which use the same entry points in the
+//! same order; what has not been checked by a compiler is this file.
+//!
+//! Drop-in use (src/main.rs:97-101):
+//! ```ignore
+//! let mut sim = nbody_hip::HipBarnesHutSimulation::<f64>::new(points, LeapFrogIntegrator::new(),
+//!                                                             Bounds::new([0.0, 0.0, 0.0].into(), box_width));
+//! ```
 #![feature(generic_const_exprs)]
 #![allow(incomplete_features)]
 
 use std::cell::{Cell, UnsafeCell};
 use std::ffi::{c_char, c_int, c_void, CStr};
 
-use nbody::shared::{Bounds, Integrator, LeapFrogIntegrator, PointParticle, Simulation, SimulationSettings, AABB};
+// the reference's library target is `nlib` (Cargo.toml: [lib] name = "nlib")
+use nlib::shared::{AABB, Bounds, Float, Integrator, LeapFrogIntegrator, Particle, PointParticle, Simulation, SimulationSettings};
 
-type P = PointParticle<f32, 3>;
-type I = LeapFrogIntegrator<f32, 3, P>;
+#[cfg(feature = "render")]
+use nlib::render::{BufferWrapper, Context, PipelineType, Renderable, Renderer};
 
 #[repr(C)]
 struct NbodyConfig {
@@ -27,15 +36,16 @@ struct NbodyConfig {
     host_threads: i32,
     capacity: u64,
     tree_build: i32,
-    reserved: i32,
+    dtype: i32,
 }
 
 #[repr(C)]
-struct NbodyHandle {
+pub struct NbodyHandle {
     _private: [u8; 0],
 }
 
-extern "C" {
+// edition 2024: extern blocks are `unsafe extern`; every item is unsafe to call
+unsafe extern "C" {
     fn nbody_create(cfg: *const NbodyConfig, out: *mut *mut NbodyHandle) -> c_int;
     fn nbody_destroy(h: *mut NbodyHandle);
     fn nbody_clone(h: *const NbodyHandle, out: *mut *mut NbodyHandle) -> c_int;
@@ -45,92 +55,235 @@ extern "C" {
     fn nbody_add_point(h: *mut NbodyHandle, particle: *const c_void) -> c_int;
     fn nbody_remove_point(h: *mut NbodyHandle, index: usize) -> c_int;
     fn nbody_set_settings(h: *mut NbodyHandle, g: f32, g_soft: f32, dt: f32, theta2: f32) -> c_int;
+    fn nbody_set_settings_f64(h: *mut NbodyHandle, g: f64, g_soft: f64, dt: f64, theta2: f64) -> c_int;
     fn nbody_set_bounds(h: *mut NbodyHandle, center: *const f32, width: f32) -> c_int;
+    fn nbody_set_bounds_f64(h: *mut NbodyHandle, center: *const f64, width: f64) -> c_int;
     fn nbody_init(h: *mut NbodyHandle) -> c_int;
     fn nbody_step_by(h: *mut NbodyHandle, dt: f32) -> c_int;
+    fn nbody_step_by_f64(h: *mut NbodyHandle, dt: f64) -> c_int;
+    fn nbody_steps(h: *mut NbodyHandle, k: c_int) -> c_int;
     fn nbody_update_forces(h: *mut NbodyHandle) -> c_int;
+    fn nbody_sync(h: *mut NbodyHandle) -> c_int;
     fn nbody_last_error(h: *const NbodyHandle) -> *const c_char;
 }
 
-const NBODY_BRUTE_FORCE: i32 = 0;
-const NBODY_BARNES_HUT: i32 = 1;
-const NBODY_MATH_FAST: i32 = 1;
+pub const NBODY_BRUTE_FORCE: i32 = 0; // src/manual/brute_force.rs
+pub const NBODY_BARNES_HUT: i32 = 1; // src/manual/barnes_hut.rs
+
+/// Arithmetic of the force kernels (include/nbody_hip.h).
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum MathMode {
+    /// the reference's rounding sequence (sqrt, (d*d)*d, g/r^3, partners in ascending order): bit-exact
+    Strict = 0,
+    /// v_rsq_f32 + FMA, partner range split over waves: <= 1e-5 relative (f32 only; f64 always runs strict)
+    Fast = 1,
+}
+
+/// Barnes-Hut leaf semantics.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum LeafMode {
+    /// src/manual/barnes_hut.rs:185-203: a leaf failing the opening test contributes nothing
+    Reference = 0,
+    /// the walk of src/llm/barnes_hut.rs:915-997 on the same tree: such a leaf is evaluated directly
+    Direct = 1,
+}
+
+/// Where the octree is built.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum TreeBuild {
+    Host = 0,
+    Device = 1,
+    /// fast math -> device, strict math -> host (the bit-exact path)
+    Auto = 2,
+}
+
+/// What `Simulation::new` cannot carry (the trait's signature is fixed): pass it to `with_options`.
+#[derive(Debug, Clone, Copy)]
+pub struct HipOptions {
+    pub math_mode: MathMode,
+    pub leaf_mode: LeafMode,
+    pub tree_build: TreeBuild,
+    /// octree-build threads (the reference's `-t`, src/main.rs:34-35); 0 = all
+    pub host_threads: i32,
+    /// HIP device ordinal; -1 = LOCAL_RANK or 0
+    pub device: i32,
+    /// max bodies (add_point may grow up to this); 0 = twice the initial count
+    pub capacity: usize,
+}
+
+impl Default for HipOptions {
+    fn default() -> Self {
+        Self { math_mode: MathMode::Fast, leaf_mode: LeafMode::Reference, tree_build: TreeBuild::Auto, host_threads: 0, device: -1, capacity: 0 }
+    }
+}
+
+mod sealed {
+    pub trait Sealed {}
+    impl Sealed for f32 {}
+    impl Sealed for f64 {}
+}
+
+/// The two instantiations of the reference's `Float` the library accepts, with their entry points.
+pub trait HipFloat: Float + sealed::Sealed {
+    const DTYPE: i32;
+    unsafe fn abi_set_settings(h: *mut NbodyHandle, s: &SimulationSettings<Self>) -> c_int;
+    unsafe fn abi_set_bounds(h: *mut NbodyHandle, center: [Self; 3], width: Self) -> c_int;
+    unsafe fn abi_step_by(h: *mut NbodyHandle, dt: Self) -> c_int;
+}
+
+impl HipFloat for f32 {
+    const DTYPE: i32 = 0; // NBODY_F32
+    unsafe fn abi_set_settings(h: *mut NbodyHandle, s: &SimulationSettings<f32>) -> c_int {
+        unsafe { nbody_set_settings(h, s.g, s.g_soft, s.dt, s.theta2) }
+    }
+    unsafe fn abi_set_bounds(h: *mut NbodyHandle, center: [f32; 3], width: f32) -> c_int {
+        unsafe { nbody_set_bounds(h, center.as_ptr(), width) }
+    }
+    unsafe fn abi_step_by(h: *mut NbodyHandle, dt: f32) -> c_int {
+        unsafe { nbody_step_by(h, dt) }
+    }
+}
+
+impl HipFloat for f64 {
+    const DTYPE: i32 = 1; // NBODY_F64
+    unsafe fn abi_set_settings(h: *mut NbodyHandle, s: &SimulationSettings<f64>) -> c_int {
+        unsafe { nbody_set_settings_f64(h, s.g, s.g_soft, s.dt, s.theta2) }
+    }
+    unsafe fn abi_set_bounds(h: *mut NbodyHandle, center: [f64; 3], width: f64) -> c_int {
+        unsafe { nbody_set_bounds_f64(h, center.as_ptr(), width) }
+    }
+    unsafe fn abi_step_by(h: *mut NbodyHandle, dt: f64) -> c_int {
+        unsafe { nbody_step_by_f64(h, dt) }
+    }
+}
+
+type P<F> = PointParticle<F, 3>;
+type I<F> = LeapFrogIntegrator<F, 3, P<F>>;
 
 /// One GPU-resident simulation.  `METHOD` selects which reference solver it stands in for.
-pub struct HipSimulation<const METHOD: i32> {
+pub struct HipSimulation<F: HipFloat, const METHOD: i32> {
     handle: *mut NbodyHandle,
     /// host mirror handed out by `get_points(&self)`; refreshed lazily (the trait borrows `&self`,
     /// hence the interior mutability)
-    points: UnsafeCell<Vec<P>>,
+    points: UnsafeCell<Vec<P<F>>>,
     dirty: Cell<bool>,
-    integrator: I,
-    bounds: Bounds<f32, 3>,
-    settings: SimulationSettings<f32>,
+    integrator: I<F>,
+    bounds: Bounds<F, 3>,
+    settings: SimulationSettings<F>,
     settings_dirty: bool,
-    elapsed: f32,
+    elapsed: F,
+    options: HipOptions,
+    #[cfg(feature = "render")]
+    points_buffer: Option<BufferWrapper>,
+    #[cfg(feature = "render")]
+    bounds_buffer: Option<BufferWrapper>,
 }
 
-pub type HipBruteForceSimulation = HipSimulation<NBODY_BRUTE_FORCE>;
-pub type HipBarnesHutSimulation = HipSimulation<NBODY_BARNES_HUT>;
+pub type HipBruteForceSimulation<F> = HipSimulation<F, NBODY_BRUTE_FORCE>;
+pub type HipBarnesHutSimulation<F> = HipSimulation<F, NBODY_BARNES_HUT>;
 
-impl<const METHOD: i32> HipSimulation<METHOD> {
+fn last_error(h: *const NbodyHandle) -> String {
+    unsafe { CStr::from_ptr(nbody_last_error(h)) }.to_string_lossy().into_owned()
+}
+
+impl<F: HipFloat, const METHOD: i32> HipSimulation<F, METHOD> {
     fn check(&self, rc: c_int) {
         if rc != 0 {
             // the reference's trait is infallible (it unwraps); keep that contract
-            let msg = unsafe { CStr::from_ptr(nbody_last_error(self.handle)) }.to_string_lossy().into_owned();
-            panic!("nbody_hip error {rc}: {msg}");
+            panic!("nbody_hip error {rc}: {}", last_error(self.handle));
         }
     }
 
     fn push_settings(&mut self) {
         if self.settings_dirty {
-            let s = &self.settings;
-            self.check(unsafe { nbody_set_settings(self.handle, s.g, s.g_soft, s.dt, s.theta2) });
+            let rc = unsafe { F::abi_set_settings(self.handle, &self.settings) };
+            self.check(rc);
             self.settings_dirty = false;
         }
     }
 
-    fn create(points: &[P], bounds: &Bounds<f32, 3>) -> *mut NbodyHandle {
+    fn create(points: &[P<F>], bounds: &Bounds<F, 3>, o: &HipOptions) -> *mut NbodyHandle {
         let cfg = NbodyConfig {
             struct_size: std::mem::size_of::<NbodyConfig>() as u32,
             method: METHOD,
-            math_mode: NBODY_MATH_FAST,
-            leaf_mode: 0, // NBODY_LEAF_REFERENCE (src/manual); 1 = NBODY_LEAF_DIRECT (the src/llm walk)
-            device: -1,
+            math_mode: o.math_mode as i32,
+            leaf_mode: o.leaf_mode as i32,
+            device: o.device,
             rank: 0,
             world_size: 1,
-            host_threads: 0,
-            capacity: (points.len().max(1) * 2) as u64, // headroom for add_point
-            tree_build: 0,
-            reserved: 0,
+            host_threads: o.host_threads,
+            capacity: if o.capacity > 0 { o.capacity as u64 } else { (points.len().max(1) * 2) as u64 }, // headroom for add_point
+            tree_build: o.tree_build as i32,
+            dtype: F::DTYPE,
         };
         let mut h: *mut NbodyHandle = std::ptr::null_mut();
         let rc = unsafe { nbody_create(&cfg, &mut h) };
         if rc != 0 {
-            let msg = unsafe { CStr::from_ptr(nbody_last_error(std::ptr::null())) }.to_string_lossy().into_owned();
-            panic!("nbody_create failed ({rc}): {msg}");
+            panic!("nbody_create failed ({rc}): {}", last_error(std::ptr::null()));
         }
-        let c = bounds.center();
-        let center = [c[0], c[1], c[2]];
-        unsafe {
-            assert_eq!(nbody_set_bounds(h, center.as_ptr(), bounds.width), 0);
-            // PointParticle<f32,3> is #[repr(C)] {position, velocity, acceleration, mass}: 40 bytes
-            assert_eq!(nbody_upload(h, points.as_ptr() as *const c_void, points.len(), std::mem::size_of::<P>()), 0);
-        }
+        let c = bounds.center(); // AABB::center (shared.rs:233-235)
+        let rc = unsafe { F::abi_set_bounds(h, [c[0], c[1], c[2]], bounds.width) };
+        assert_eq!(rc, 0, "nbody_set_bounds: {}", last_error(h));
+        // PointParticle<F,3> is #[repr(C)] {position, velocity, acceleration, mass}: 40 bytes (f32) / 80 bytes (f64)
+        let rc = unsafe { nbody_upload(h, points.as_ptr() as *const c_void, points.len(), std::mem::size_of::<P<F>>()) };
+        assert_eq!(rc, 0, "nbody_upload: {}", last_error(h));
         h
+    }
+
+    /// `Simulation::new` with the choices the trait's signature has no room for.
+    pub fn with_options(points: Vec<P<F>>, integrator: I<F>, bounds: Bounds<F, 3>, options: HipOptions) -> Self {
+        let handle = Self::create(&points, &bounds, &options);
+        Self {
+            handle,
+            points: UnsafeCell::new(points),
+            dirty: Cell::new(false),
+            integrator,
+            bounds,
+            settings: SimulationSettings::default(),
+            settings_dirty: true,
+            elapsed: F::from(0.0).unwrap(),
+            options,
+            #[cfg(feature = "render")]
+            points_buffer: None,
+            #[cfg(feature = "render")]
+            bounds_buffer: None,
+        }
+    }
+
+    /// k x `step()` with no host round trip in between (the headless loop of src/main.rs:119-122).
+    pub fn steps(&mut self, k: usize) {
+        self.push_settings();
+        let rc = unsafe { nbody_steps(self.handle, k as c_int) };
+        self.check(rc);
+        let dt = self.settings.dt;
+        for _ in 0..k {
+            self.elapsed += dt;
+        }
+        self.dirty.set(true);
+    }
+
+    /// Blocks until everything enqueued has finished (call before reading a host clock).
+    pub fn sync(&mut self) {
+        let rc = unsafe { nbody_sync(self.handle) };
+        self.check(rc);
+    }
+
+    pub fn options(&self) -> &HipOptions {
+        &self.options
     }
 }
 
-impl<const METHOD: i32> Drop for HipSimulation<METHOD> {
+impl<F: HipFloat, const METHOD: i32> Drop for HipSimulation<F, METHOD> {
     fn drop(&mut self) {
         unsafe { nbody_destroy(self.handle) }
     }
 }
 
-impl<const METHOD: i32> Clone for HipSimulation<METHOD> {
+impl<F: HipFloat, const METHOD: i32> Clone for HipSimulation<F, METHOD> {
     fn clone(&self) -> Self {
         let mut h: *mut NbodyHandle = std::ptr::null_mut();
-        self.check(unsafe { nbody_clone(self.handle, &mut h) });
+        let rc = unsafe { nbody_clone(self.handle, &mut h) };
+        self.check(rc);
         Self {
             handle: h,
             points: UnsafeCell::new(Vec::new()),
@@ -140,82 +293,141 @@ impl<const METHOD: i32> Clone for HipSimulation<METHOD> {
             settings: self.settings.clone(),
             settings_dirty: true,
             elapsed: self.elapsed,
+            options: self.options,
+            #[cfg(feature = "render")]
+            points_buffer: self.points_buffer.clone(),
+            #[cfg(feature = "render")]
+            bounds_buffer: self.bounds_buffer.clone(),
         }
     }
 }
 
-impl<const METHOD: i32> Simulation<f32, 3, P, I> for HipSimulation<METHOD> {
-    fn new(points: Vec<P>, integrator: I, bounds: Bounds<f32, 3>) -> Self {
-        let handle = Self::create(&points, &bounds);
-        Self {
-            handle,
-            points: UnsafeCell::new(points),
-            dirty: Cell::new(false),
-            integrator,
-            bounds,
-            settings: SimulationSettings::default(),
-            settings_dirty: true,
-            elapsed: 0.0,
-        }
+impl<F: HipFloat, const METHOD: i32> Simulation<F, 3, P<F>, I<F>> for HipSimulation<F, METHOD> {
+    fn new(points: Vec<P<F>>, integrator: I<F>, bounds: Bounds<F, 3>) -> Self {
+        Self::with_options(points, integrator, bounds, HipOptions::default())
     }
 
     fn init(&mut self) {
         self.integrator.init();
-        self.elapsed = 0.0;
-        self.check(unsafe { nbody_init(self.handle) });
+        self.elapsed = F::from(0.0).unwrap();
+        let rc = unsafe { nbody_init(self.handle) };
+        self.check(rc);
     }
 
-    fn step_by(&mut self, dt: f32) {
+    fn step_by(&mut self, dt: F) {
         self.push_settings();
-        self.check(unsafe { nbody_step_by(self.handle, dt) });
+        let rc = unsafe { F::abi_step_by(self.handle, dt) };
+        self.check(rc);
         self.elapsed += dt;
         self.dirty.set(true);
     }
 
     fn update_forces(&mut self) {
         self.push_settings();
-        self.check(unsafe { nbody_update_forces(self.handle) });
+        let rc = unsafe { nbody_update_forces(self.handle) };
+        self.check(rc);
         self.dirty.set(true);
     }
 
-    fn add_point(&mut self, point: P) {
-        self.check(unsafe { nbody_add_point(self.handle, &point as *const P as *const c_void) });
+    fn add_point(&mut self, point: P<F>) {
+        let rc = unsafe { nbody_add_point(self.handle, &point as *const P<F> as *const c_void) };
+        self.check(rc);
         self.dirty.set(true);
     }
 
     fn remove_point(&mut self, index: usize) {
-        self.check(unsafe { nbody_remove_point(self.handle, index) });
+        let rc = unsafe { nbody_remove_point(self.handle, index) };
+        self.check(rc);
         self.dirty.set(true);
     }
 
-    fn get_points(&self) -> &Vec<P> {
+    fn get_points(&self) -> &Vec<P<F>> {
         // SAFETY: single-threaded use (the reference calls its simulation from one thread); the
         // vector is only replaced here, never while a previously returned borrow can be live
         // across a &mut self call.
         let v = unsafe { &mut *self.points.get() };
         if self.dirty.get() {
             let mut n: usize = 0;
-            self.check(unsafe { nbody_count(self.handle, &mut n) });
-            v.resize(n, P::new([0.0; 3].into(), [0.0; 3].into(), 0.0, 0.0));
-            self.check(unsafe {
-                nbody_download(self.handle, v.as_mut_ptr() as *mut c_void, n, std::mem::size_of::<P>(), &mut n)
-            });
+            let rc = unsafe { nbody_count(self.handle, &mut n) };
+            self.check(rc);
+            let zero = F::from(0.0).unwrap();
+            v.resize(n, P::<F>::new([zero; 3].into(), [zero; 3].into(), zero, zero));
+            let rc = unsafe { nbody_download(self.handle, v.as_mut_ptr() as *mut c_void, n, std::mem::size_of::<P<F>>(), &mut n) };
+            self.check(rc);
             v.truncate(n);
             self.dirty.set(false);
         }
         v
     }
 
-    fn elapsed(&self) -> f32 {
+    fn elapsed(&self) -> F {
         self.elapsed
     }
 
-    fn settings(&self) -> &SimulationSettings<f32> {
+    fn settings(&self) -> &SimulationSettings<F> {
         &self.settings
     }
 
-    fn settings_mut(&mut self) -> &mut SimulationSettings<f32> {
-        self.settings_dirty = true;
+    fn settings_mut(&mut self) -> &mut SimulationSettings<F> {
+        self.settings_dirty = true; // pushed to the device before the next step (src/vis.rs:148-187 edits these live)
         &mut self.settings
+    }
+}
+
+/// The visualiser's side (src/vis.rs:25-30 wants `Simulation + Renderable`): what
+/// src/manual/brute_force.rs:105-171 does, over the positions synced back on demand by `get_points()`.
+#[cfg(feature = "render")]
+impl<F: HipFloat, const METHOD: i32> Renderable for HipSimulation<F, METHOD> {
+    fn render(&mut self, renderer: &mut Renderer) {
+        if self.points_buffer.is_some() {
+            // brute_force.rs:116-125: every position component cast F -> f32, three per body
+            let point_position_data: Vec<f32> = self
+                .get_points()
+                .iter()
+                .flat_map(|p| p.position().iter().map(|x| num_traits::cast::<F, f32>(*x).unwrap()).collect::<Vec<f32>>())
+                .collect();
+            let n_points = (point_position_data.len() / 3) as u32;
+            let points_buffer = self.points_buffer.as_mut().unwrap();
+            points_buffer.update(&renderer.context, point_position_data.as_slice());
+
+            renderer.set_pipeline(PipelineType::Points);
+            let render_pass = renderer.get_render_pass();
+            render_pass.set_vertex_buffer(0, points_buffer.buffer.slice(..));
+            render_pass.draw(0..4, 0..n_points); // a 4-vertex strip per body (brute_force.rs:132)
+        }
+
+        if let Some(ref mut bounds_buffer) = self.bounds_buffer {
+            // brute_force.rs:135-153: min corner, max corner, colour
+            let mut bounds_data = [self.bounds.min(), self.bounds.max()]
+                .iter()
+                .flat_map(|p| p.iter().map(|x| num_traits::cast::<F, f32>(*x).unwrap()).collect::<Vec<f32>>())
+                .collect::<Vec<f32>>();
+            let color = [0.0, 1.0, 0.0, 1.0];
+            bounds_data.extend(color);
+
+            bounds_buffer.update(&renderer.context, bounds_data.as_slice());
+
+            renderer.set_pipeline(PipelineType::AABB);
+            let render_pass: &mut wgpu::RenderPass<'_> = renderer.get_render_pass();
+            render_pass.set_vertex_buffer(0, bounds_buffer.buffer.slice(..));
+            render_pass.draw(0..16, 0..1);
+        }
+    }
+
+    fn render_init(&mut self, context: &Context) {
+        // brute_force.rs:156-170
+        self.points_buffer = Some(BufferWrapper::new(
+            &context.device,
+            Some("Point Buffer"),
+            &[] as &[f32],
+            wgpu::BufferUsages::VERTEX | wgpu::BufferUsages::COPY_DST,
+        ));
+
+        self.bounds_buffer = Some(BufferWrapper::new(
+            &context.device,
+            Some("Bounds Buffer"),
+            &[] as &[f32],
+            wgpu::BufferUsages::VERTEX | wgpu::BufferUsages::COPY_DST,
+        ));
     }
 }

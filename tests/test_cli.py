@@ -25,7 +25,8 @@ def test_cli_rejects_unknown_flags():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--tree", "device"], ["--method", "bf", "--ic", "plummer"]])
+@pytest.mark.parametrize("extra", [[], ["--tree", "device"], ["--tree", "host"], ["--method", "bf", "--ic", "plummer"], ["--dtype", "f64"],
+                                   ["--dtype", "f64", "--method", "bf", "--ic", "plummer"]])
 def test_cli_reference_argv_and_output_lines(gpu, extra):
     r = subprocess.run([CLI, "-t", "4", "-n", "3000", "--steps", "50"] + extra, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
