@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 2
+#define NBODY_ABI_VERSION 3
 
 typedef struct NbodyHandle NbodyHandle;
 
@@ -78,6 +78,12 @@ enum { NBODY_F32 = 0,  /* PointParticle<f32,3>: every path of this library */
                           host build; positions, velocities, accelerations and node counts bit-equal to the reference's
                           rounding sequence in f64 (oracle/: the same templated restatement) */
 
+/* how the bodies are dealt to the shards of a multi-GPU run */
+enum { NBODY_SHARD_INDEX = 0,   /* contiguous index blocks of the vector; positions all-gathered every step (every method) */
+       NBODY_SHARD_SPATIAL = 1 }; /* Barnes-Hut, fast math, device build: ownership by Morton-key range (bodies that cross a
+                                   boundary migrate), every rank builds only its slice of the tree and receives from each
+                                   partner the nodes its own bodies can reach ("halo" / locally essential tree): configs[4] */
+
 typedef struct NbodyConfig {
     uint32_t struct_size;  /* = sizeof(NbodyConfig) */
     int32_t method;        /* NBODY_BRUTE_FORCE | NBODY_BARNES_HUT */
@@ -90,6 +96,8 @@ typedef struct NbodyConfig {
     uint64_t capacity;     /* max bodies over ALL shards (add_point may grow up to this) */
     int32_t tree_build;    /* NBODY_TREE_HOST | NBODY_TREE_DEVICE | NBODY_TREE_AUTO (Barnes-Hut only) */
     int32_t dtype;         /* NBODY_F32 (0, the default) | NBODY_F64 */
+    int32_t shard_mode;    /* NBODY_SHARD_INDEX (0, the default) | NBODY_SHARD_SPATIAL; struct_size may also be the 48 bytes of */
+    int32_t reserved;      /* ABI versions <= 2, which end before this field */
 } NbodyConfig;
 
 typedef struct NbodyStats {
@@ -182,6 +190,21 @@ int nbody_comm_unique_id(void* id_bytes);
 int nbody_comm_init(NbodyHandle* h, const void* id_bytes);
 /* first global index and length of this rank's block at upload time */
 int nbody_local_range(const NbodyHandle* h, size_t* first, size_t* count);
+/* NBODY_SHARD_SPATIAL: a rank's bodies are not an index block (and change as bodies migrate).  This gives, in the
+ * order nbody_download writes the bodies, each one's index in the uploaded vector: scattering all ranks' bodies by it
+ * restores the reference's vector order (Vec::retain keeps relative order, so the indices stay ascending there). */
+int nbody_download_ids(NbodyHandle* h, int32_t* ids, size_t cap, size_t* n_out);
+typedef struct NbodyLetStats {
+    uint64_t steps;             /* force passes counted */
+    uint64_t bodies_migrated;   /* bodies this rank sent to another rank */
+    uint64_t nodes_local;       /* nodes of this rank's slice, summed over the passes */
+    uint64_t nodes_global;      /* nodes of the whole tree, summed */
+    uint64_t nodes_sent;        /* node records this rank exported, summed over partners and passes */
+    uint64_t nodes_received;    /* node records it imported */
+    uint64_t bytes_sent;        /* bytes of all four exchanges this rank sent (migrants, end info, spanning-cell tables, nodes) */
+    uint64_t bytes_allgather_equivalent; /* what the index-block scheme sends per rank for the same passes: 16 B per own body */
+} NbodyLetStats;
+int nbody_let_stats(NbodyHandle* h, NbodyLetStats* out);
 
 /* ---- synthetic initial conditions (host side; what src/main.rs:52-89 does for the disc) ----- */
 /* Plummer sphere, G = M = 1, Henon units, equal masses 1/n, centre of mass at rest at the origin. */
@@ -204,6 +227,13 @@ int nbody_debug_import_segment(NbodyHandle* h, NbodyHandle* peer);
 int nbody_debug_step_forces(NbodyHandle* h, float dt);
 int nbody_debug_import_partials(NbodyHandle* h, NbodyHandle* peer);
 int nbody_debug_step_end(NbodyHandle* h, float dt);
+/* the same for NBODY_SHARD_SPATIAL handles: phases 0..4 of a step (drift + retain + pick migrants | take migrants in +
+ * sort | emit the slice + spanning-cell table | finish the spanning cells + pick and pack the nodes partners need |
+ * place imports + walk + kick), and between them the four exchanges as copies from `peer` (which = 0 migrants,
+ * 1 end info, 2 spanning-cell tables, 3 nodes).  prune = 0 in nbody_debug_let_set_prune exports every private node. */
+int nbody_debug_let_phase(NbodyHandle* h, int phase, float dt);
+int nbody_debug_let_exchange(NbodyHandle* h, NbodyHandle* peer, int which);
+int nbody_debug_let_set_prune(NbodyHandle* h, int prune);
 
 /* ---- host-only entry (no device needed): the plan of the symmetric scheme across shards ---------- */
 /* Which pairs between shards `rank` evaluates (rows {shard, first chunk, last chunk, first own set,

@@ -53,6 +53,7 @@ PARTICLE_DTYPE64 = np.dtype(
 )
 assert PARTICLE_DTYPE64.itemsize == 80
 F32, F64 = 0, 1
+SHARD_INDEX, SHARD_SPATIAL = 0, 1   # index blocks + all-gather | Morton-key ranges + halo exchange (Barnes-Hut, fast math)
 
 #: every symbol include/nbody_hip.h declares (tests check the library exports all of them)
 DECLARED_SYMBOLS = [
@@ -66,6 +67,7 @@ DECLARED_SYMBOLS = [
     "nbody_debug_import_partials", "nbody_debug_step_end", "nbody_host_cross_plan",
     "nbody_set_settings_f64", "nbody_get_settings_f64", "nbody_set_bounds_f64", "nbody_step_by_f64", "nbody_elapsed_f64",
     "nbody_tree_export_f64", "nbody_ic_plummer_f64", "nbody_ic_disc_f64",
+    "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
 ]
 
 
@@ -73,8 +75,13 @@ class NbodyConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("method", C.c_int32), ("math_mode", C.c_int32), ("leaf_mode", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("host_threads", C.c_int32),
-        ("capacity", C.c_uint64), ("tree_build", C.c_int32), ("dtype", C.c_int32),
+        ("capacity", C.c_uint64), ("tree_build", C.c_int32), ("dtype", C.c_int32), ("shard_mode", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+class NbodyLetStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("steps", "bodies_migrated", "nodes_local", "nodes_global", "nodes_sent", "nodes_received",
+                                          "bytes_sent", "bytes_allgather_equivalent")]
 
 
 class NbodyStats(C.Structure):
@@ -145,6 +152,11 @@ _sig("nbody_elapsed_f64", _i, _H, _pd)
 _sig("nbody_tree_export_f64", _i, _H, C.c_void_p, C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz))
 _sig("nbody_ic_plummer_f64", _i, C.c_void_p, _sz, _sz, C.c_uint64)
 _sig("nbody_ic_disc_f64", _i, C.c_void_p, _sz, _sz, C.c_uint64)
+_sig("nbody_download_ids", _i, _H, C.c_void_p, _sz, C.POINTER(_sz))
+_sig("nbody_let_stats", _i, _H, C.POINTER(NbodyLetStats))
+_sig("nbody_debug_let_phase", _i, _H, _i, _f)
+_sig("nbody_debug_let_exchange", _i, _H, _H, _i)
+_sig("nbody_debug_let_set_prune", _i, _H, _i)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
 
@@ -230,7 +242,7 @@ class Simulation:
     def __init__(self, points: np.ndarray, center=(0.0, 0.0, 0.0), width: float = 1.0, *, method: int = BRUTE_FORCE,
                  math_mode: int = STRICT, capacity: int | None = None, device: int = -1, rank: int = 0,
                  world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_AUTO, leaf_mode: int = LEAF_REFERENCE,
-                 f64: bool | None = None, _handle=None, _f64: bool = False):
+                 f64: bool | None = None, shard_mode: int = SHARD_INDEX, _handle=None, _f64: bool = False):
         self._h = _H()
         self.f64 = bool(_f64)
         if _handle is not None:
@@ -242,7 +254,7 @@ class Simulation:
         points = np.ascontiguousarray(points, dtype=self.dtype)
         cfg = NbodyConfig(C.sizeof(NbodyConfig), method, math_mode, leaf_mode, device, rank, world_size,
                           host_threads, int(capacity if capacity is not None else max(1, points.shape[0])), tree_build,
-                          F64 if self.f64 else F32)
+                          F64 if self.f64 else F32, shard_mode, 0)
         rc = lib.nbody_create(C.byref(cfg), C.byref(self._h))
         if rc:
             self._h = _H()
@@ -385,6 +397,22 @@ class Simulation:
         self._check(export(self._h, com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, C.byref(n)))
         return dict(com_mass=com, width=w, skip=skip)
 
+    def download_ids(self) -> np.ndarray:
+        """NBODY_SHARD_SPATIAL: index in the uploaded vector of every body get_points() returns, in the same order."""
+        n = C.c_size_t(0)
+        self._check(lib.nbody_count(self._h, C.byref(n)))
+        ids = np.zeros(n.value, np.int32)
+        self._check(lib.nbody_download_ids(self._h, ids.ctypes.data, n.value, C.byref(n)))
+        return ids[: n.value]
+
+    def let_stats(self) -> NbodyLetStats:
+        s = NbodyLetStats()
+        self._check(lib.nbody_let_stats(self._h, C.byref(s)))
+        return s
+
+    def set_prune(self, on: bool):
+        self._check(lib.nbody_debug_let_set_prune(self._h, int(bool(on))))
+
     def local_range(self) -> tuple[int, int]:
         a, b = C.c_size_t(0), C.c_size_t(0)
         self._check(lib.nbody_local_range(self._h, C.byref(a), C.byref(b)))
@@ -414,6 +442,35 @@ def sharded_step(sims: list, dt: float | None = None):
                 s._check(lib.nbody_debug_import_partials(s._h, peer._h))
     for s, d in zip(sims, dts):
         s._check(lib.nbody_debug_step_end(s._h, d))
+
+
+def spatial_step(sims: list, dt: float | None = None, forces_only: bool = False):
+    """One step (or, forces_only, one update_forces) of a world of len(sims) NBODY_SHARD_SPATIAL handles living in this
+    process: the five phases of nbody_let.cpp with the four RCCL exchanges done as device-to-device copies."""
+    dts = [float(s.settings.dt if dt is None else dt) for s in sims]
+    first, last = (10, 14) if forces_only else (0, 4)
+    for phase in (first, 1, 2, 3, last):
+        for s, d in zip(sims, dts):
+            s._check(lib.nbody_debug_let_phase(s._h, phase, d))
+        if phase == last:
+            break
+        which = {first: 0, 1: 1, 2: 2, 3: 3}[phase]
+        for s in sims:
+            for peer in sims:
+                if peer is not s:
+                    s._check(lib.nbody_debug_let_exchange(s._h, peer._h, which))
+
+
+def spatial_gather(sims: list, n: int):
+    """The world's bodies back in the uploaded vector's order: (records, indices that survived)."""
+    parts, ids = [], []
+    for s in sims:
+        parts.append(s.get_points())
+        ids.append(s.download_ids())
+    rec = np.concatenate(parts)
+    idx = np.concatenate(ids)
+    order = np.argsort(idx, kind="stable")
+    return rec[order], idx[order]
 
 
 def host_cross_plan(rank: int, world: int, seg_cap: int, n_own: int) -> dict:

@@ -24,6 +24,7 @@ struct Shard {
     // host: deeper than the device build's 21 levels, or more nodes than allocated) -- every kernel that changes the
     // state then does nothing until the host has dealt with it; [1] = steps completed since the host last looked
     int* poison = nullptr;
+    int* ids = nullptr;                         // [seg_cap] spatial shards: index of each own body in the uploaded vector (moves with it)
     unsigned long long* inter = nullptr;        // [1] brute force: directed interactions evaluated, n_own * (n_total - 1) per force pass from the LIVE counts
     int n_seg = 1;
     int seg_cap = 0;
@@ -131,10 +132,12 @@ struct TreeDev {
     size_t bfs_cap = 0;              // nodes both are sized for
 };
 // device-side octree build (kernels_tree.hip)
-struct TreeDevWork {  // arrays of the last build the split-point kernel needs
-    const unsigned long long* keys = nullptr;
-    const signed char* delta = nullptr;
-    const int* base = nullptr;
+struct TreeDevWork {  // arrays of the last build (inside its workspace)
+    const unsigned long long* keys = nullptr;   // sorted keys
+    const signed char* delta = nullptr;         // levels shared by neighbouring sorted bodies
+    const int* base = nullptr;                  // first node of every sorted body
+    const int* ids = nullptr;                   // sorted position -> body
+    const void* incl = nullptr;                 // inclusive f64 prefix sums {m, m x, m y, m z} over the sorted bodies (4 doubles each)
 };
 struct TreeCat {  // sharded runs: side buffer of the device build
     float4* pos = nullptr;     // live bodies of all segments, concatenated in segment order
@@ -155,6 +158,11 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
 // level-order copy of a pre-order node array for the cooperative block walk
 size_t bfs_workspace_bytes(size_t n_cap);
 int build_bfs_layout(hipStream_t s, const float4* nodes, int n_nodes, void* workspace, size_t n_cap, float4* out);
+// the build in two halves (spatial shards need the sorted keys of all ranks' ends before the second one)
+int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
+                   void* workspace, size_t n_cap, int* out_info, TreeDevWork* work);
+int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
+                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge);
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
                            int* n_anc, int* anc, int max_anc, const int* info = nullptr /* device: {n_nodes, flags, n}: overrides n, n_nodes */,
                            int* poison = nullptr /* made sticky when the build raised a flag */);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kCompactTile) void k_compact(float4* __restrict__ p
                                                           float4* __restrict__ acc, const unsigned char* __restrict__ keep,
                                                           int* __restrict__ count, int* __restrict__ escaped,
                                                           unsigned long long* __restrict__ tile_state, int* __restrict__ epoch_p,
-                                                          const int* __restrict__ poison) {
+                                                          const int* __restrict__ poison, int* __restrict__ ids) {
     if (poison && *poison) return;
     if (*escaped == 0) return;
     __shared__ int wave_total[16];
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kCompactTile) void k_compact(float4* __restrict__ p
     const int k = tile * kCompactTile + tid;
     const bool kp = (k < n) && keep[k];
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p, a = p;
-    if (kp) { p = pos[k]; v = vel[k]; a = acc[k]; }
+    int id = 0;
+    if (kp) { p = pos[k]; v = vel[k]; a = acc[k]; if (ids) id = ids[k]; }
     const unsigned long long m = __ballot(kp);
     const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wave_total[wave] = __popcll(m);
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(kCompactTile) void k_compact(float4* __restrict__ p
     if (kp) {
         const int d = excl_s + before + in_wave;
         pos[d] = p; vel[d] = v; acc[d] = a;
+        if (ids) ids[d] = id;
     }
 }
 
@@ -174,7 +176,7 @@ void launch_drift_half(hipStream_t s, const Shard& sh, int n_upper, float dt, Bo
 void launch_compact(hipStream_t s, const Shard& sh, int n_upper) {
     if (n_upper <= 0) return;
     hipLaunchKernelGGL(k_compact, dim3(blocks_for(n_upper, kCompactTile)), dim3(kCompactTile), 0, s, sh.own_pos(), sh.vel, sh.acc,
-                       sh.keep, sh.own_count(), sh.escaped, sh.tile_state, sh.epoch, sh.poison);
+                       sh.keep, sh.own_count(), sh.escaped, sh.tile_state, sh.epoch, sh.poison, sh.ids);
 }
 void launch_kick_drift(hipStream_t s, const Shard& sh, int n_upper, float dt) {
     // (launched even for an empty shard: the step counter of an unsynchronised run rides in it)

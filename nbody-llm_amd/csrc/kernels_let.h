@@ -1,0 +1,58 @@
+// kernels_let.h -- launchers and wire structs of the spatial-shard (halo exchange) Barnes-Hut path; see kernels_let.hip.
+#pragma once
+#include "kernels.h"
+
+namespace nbody {
+namespace let {
+
+constexpr int kLevels = 21;     // levels of the device build's keys
+constexpr int kMaxRanks = 16;
+
+enum { kFlagDeep = 1, kFlagNodeCapLocal = 2, kFlagMigOverflow = 4, kFlagCapacity = 8, kFlagNodeCap = 16, kFlagLetOverflow = 32 };
+
+struct Migrant {                // a body on its way to the rank that owns its key range (64 bytes)
+    float4 pos, vel, acc;
+    int id, pad[3];
+};
+
+struct EndInfo {                // what every rank tells the others after its sort (48 bytes, all-gathered)
+    unsigned long long first_key, last_key;   // of its sorted bodies
+    int n_bodies, pad;
+    float lo[3], hi[3];                       // bounding box of its bodies
+};
+
+struct Contrib {                // [r][d]: what a rank adds to the cell of depth d on rank r's LAST body's path (40 bytes)
+    double m, mx, my, mz;       // sums over its bodies inside that cell
+    int cnt;                    // how many of them
+    int base_after;             // r != self: index in its slice of the first node behind them (its node count if none);
+                                // r == self: index in its slice of the cell itself, -1 if the cell is not its own
+};
+
+struct RoundB {                 // what every rank tells the others after its local emit (all-gathered)
+    int n_nodes, flags, pad[2];
+    Contrib c[kMaxRanks][kLevels];
+};
+
+struct LetRecord {              // an exported node: the record and where it goes in the global array (48 bytes)
+    float4 a, b;
+    int index, pad[3];
+};
+
+void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float center[3], float width, const unsigned long long* bounds,
+                     int G, int me, Migrant* send, int* send_count, int mig_cap, int* flags);
+void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, const int* recv_count, int G, int mig_cap, int* flags,
+                   int* new_count, int* send_count);
+void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, int* box_ord, EndInfo* mine);
+void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge);
+void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
+                    RoundB* mine);
+void launch_finalize(hipStream_t s, const float4* local_nodes, int local_cap, const int* info, const RoundB* rb, const EndInfo* ends, int G,
+                     int me, float width, float4* global_nodes, int global_cap, int* offsets, int* top_index, int* out_flags);
+void launch_flags_and_pack(hipStream_t s, const Shard& sh, const TreeDevWork& w, int local_cap, const int* info, const int* edge,
+                           const float4* global_nodes, const int* offsets, const int* top_index, const EndInfo* ends, int G, int me,
+                           float theta2, int* parent, unsigned char* depth, unsigned int* upper_ok, unsigned int* flags, int* let_count,
+                           LetRecord* send, size_t send_stride, int* cursor, bool prune);
+void launch_scatter(hipStream_t s, const LetRecord* recv, int n, float4* global_nodes, int global_cap);
+
+}  // namespace let
+}  // namespace nbody

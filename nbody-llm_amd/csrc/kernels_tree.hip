@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
                                                    const int* __restrict__ count, const signed char* __restrict__ delta,
                                                    const int* __restrict__ base, const Sum4* __restrict__ incl,
                                                    float width, float4* __restrict__ nodes, int node_cap,
-                                                   int* __restrict__ order, int* __restrict__ out_info, int want_hot) {
+                                                   int* __restrict__ order, int* __restrict__ out_info, int want_hot,
+                                                   const int* __restrict__ edge) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
     if (n == 0) {  // the reference's empty root (barnes_hut.rs:145)
@@ -95,7 +96,13 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
         }
         return;
     }
-    const int total = base[n - 1] + 1;  // the last sorted body opens no cell: only its leaf follows base[n-1]
+    // nodes in all: the last sorted body's first node + what it emits -- its leaf, and in a rank's slice of a distributed
+    // build (edge != null) the cells it opens with the next rank's first body (a whole tree's last body opens none)
+    int total = base[n - 1] + 1;
+    if (edge) {
+        const int dp_last = n > 1 ? delta[n - 2] : edge[0];
+        total += max(0, int(delta[n - 1]) - dp_last);
+    }
     if (idx == 0) { out_info[0] = total; out_info[2] = n; }  // (the live body count rides along: one read-back)
     if (total > node_cap) { if (idx == 0) atomicOr(out_info + 1, 2); return; }
     if (idx >= total) return;
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
     }
     const int k = lo;
     const int d_next = delta[k];
-    const int d_prev = (k > 0) ? delta[k - 1] : -1;
+    const int d_prev = (k > 0) ? delta[k - 1] : (edge ? edge[0] : -1);
     const int opened = max(0, d_next - d_prev);
     const int t = idx - base[k];
     const unsigned long long key = keys[k];
@@ -241,9 +248,13 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
                                                                      const int* __restrict__ ids, const float4* __restrict__ pos,
                                                                      const int* __restrict__ count, signed char* __restrict__ delta,
                                                                      int* __restrict__ emit_count, Sum4* __restrict__ sums,
-                                                                     int* __restrict__ flags, ScanItem* __restrict__ totals) {
+                                                                     int* __restrict__ flags, ScanItem* __restrict__ totals,
+                                                                     const int* __restrict__ edge) {
     __shared__ ScanItem lds[kScanThreads];
     const int n = *count;
+    // spatial shards (nbody_let.cpp): this rank's sorted bodies are a contiguous piece of the GLOBAL sorted order, and
+    // its first and last body have a neighbour on another rank: edge[0] / edge[1] = levels they share with it (-1: none)
+    const int edge_prev = edge ? edge[0] : -1, edge_next = edge ? edge[1] : -1;
     const int k0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     ScanItem v = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
 #pragma unroll
@@ -251,8 +262,8 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
         const int k = k0 + q;
         if (k >= n) break;
         const unsigned long long key = keys[k];
-        const int d_next = (k + 1 < n) ? common_levels(key, keys[k + 1]) : -1;
-        const int d_prev = (k > 0) ? common_levels(keys[k - 1], key) : -1;
+        const int d_next = (k + 1 < n) ? common_levels(key, keys[k + 1]) : edge_next;
+        const int d_prev = (k > 0) ? common_levels(keys[k - 1], key) : edge_prev;
         if (d_next >= kLevels) atomicOr(flags, 1);  // two bodies share all 21 levels: too deep for this build
         delta[k] = (signed char)d_next;
         const int ec = max(0, d_next - d_prev) + 1;  // opened cells + the leaf
@@ -367,44 +378,74 @@ size_t tree_build_workspace_bytes(size_t n_cap) {
     return scratch_bytes(n_cap) + 2 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
 }
 
+namespace {
+struct BuildLayout {
+    void* tmp; size_t tmp_bytes;
+    unsigned long long *keys_in, *keys;
+    int *ids_in, *ids, *emit_count, *base;
+    signed char* delta;
+    Sum4 *sums, *incl;
+};
+BuildLayout build_layout(void* workspace, size_t n_cap) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    char* p = static_cast<char*>(workspace);
+    BuildLayout L;
+    L.tmp_bytes = scratch_bytes(n_cap);
+    L.tmp = p; p += L.tmp_bytes;
+    L.keys_in = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
+    L.keys = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
+    L.ids_in = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    L.ids = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    L.emit_count = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    L.base = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    L.delta = reinterpret_cast<signed char*>(p); p += al(n_cap);
+    L.sums = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
+    L.incl = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
+    return L;
+}
+}  // namespace
+
+// First half of the build: keys and the sort.  work->keys / work->ids = the sorted (key, body) pairs.
+int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
+                   void* workspace, size_t n_cap, int* out_info, TreeDevWork* work) {
+    const BuildLayout L = build_layout(workspace, n_cap);
+    work->keys = L.keys; work->delta = L.delta; work->base = L.base; work->ids = L.ids; work->incl = L.incl;
+    const int n = n_upper;
+    if (n <= 0) { (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s); return 0; }  // (k_tree_keys clears it otherwise)
+    hipLaunchKernelGGL(k_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, n, center[0], center[1], center[2], width,
+                       L.keys_in, L.ids_in, out_info);
+    size_t tb = L.tmp_bytes;
+    if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
+    return 0;
+}
+
+// Second half: delta, scans, emit.  edge (device, 2 ints, may be null): levels the first / last sorted body shares with
+// its neighbour on another rank (spatial shards), see k_tree_delta_totals.
+int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
+                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge) {
+    const BuildLayout L = build_layout(workspace, n_cap);
+    const int n = n_upper;
+    if (n > 0) {
+        const int n_tiles = (n + kScanTile - 1) / kScanTile;
+        ScanItem* totals = static_cast<ScanItem*>(L.tmp);   // (the sort is done with its scratch)
+        hipLaunchKernelGGL(k_tree_delta_totals, dim3(n_tiles), dim3(kScanThreads), 0, s, L.keys, L.ids, pos, d_count, L.delta,
+                           L.emit_count, L.sums, out_info + 1, totals, edge);
+        hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, L.emit_count, L.sums, d_count, totals, L.base, L.incl);
+    }
+    // one thread per node; their number is known on the device only, so one per node the array can hold
+    // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
+    hipLaunchKernelGGL(k_tree_emit, dim3((std::max(1, node_cap) + 255) / 256), dim3(256), 0, s, L.keys, L.ids, pos, d_count, L.delta,
+                       L.base, L.incl, width, nodes, node_cap, order, out_info, want_hot, edge);
+    return 0;
+}
+
 // Enqueues the whole build on `s`.  out_info (device, 3 ints): [0] = node count, [1] = flags, [2] = bodies in the tree
 // (1: deeper than 21 levels, 2: node_cap too small).  The caller reads it back before the walk.
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
                         int* out_info, TreeDevWork* work, int want_hot) {
-    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    char* p = static_cast<char*>(workspace);
-    const size_t tmp_bytes = scratch_bytes(n_cap);
-    void* tmp = p; p += tmp_bytes;
-    auto* keys_in = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
-    auto* keys = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
-    auto* ids_in = reinterpret_cast<int*>(p); p += al(n_cap * 4);
-    auto* ids = reinterpret_cast<int*>(p); p += al(n_cap * 4);
-    auto* emit_count = reinterpret_cast<int*>(p); p += al(n_cap * 4);
-    auto* base = reinterpret_cast<int*>(p); p += al(n_cap * 4);
-    auto* delta = reinterpret_cast<signed char*>(p); p += al(n_cap);
-    auto* sums = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
-    auto* incl = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
-    work->keys = keys; work->delta = delta; work->base = base;
-
-    const int n = n_upper;
-    if (n <= 0) (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s);  // (k_tree_keys clears it otherwise)
-    const dim3 grid(std::max(1, (n + 255) / 256)), block(256);
-    if (n > 0) {
-        hipLaunchKernelGGL(k_tree_keys, grid, block, 0, s, pos, d_count, n, center[0], center[1], center[2], width, keys_in, ids_in, out_info);
-        size_t tb = tmp_bytes;
-        if (rocprim::radix_sort_pairs(tmp, tb, keys_in, keys, ids_in, ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
-        const int n_tiles = (n + kScanTile - 1) / kScanTile;
-        ScanItem* totals = static_cast<ScanItem*>(tmp);   // (the sort is done with its scratch)
-        hipLaunchKernelGGL(k_tree_delta_totals, dim3(n_tiles), dim3(kScanThreads), 0, s, keys, ids, pos, d_count, delta, emit_count,
-                           sums, out_info + 1, totals);
-        hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, emit_count, sums, d_count, totals, base, incl);
-    }
-    // one thread per node; their number is known on the device only, so one per node the array can hold
-    // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
-    hipLaunchKernelGGL(k_tree_emit, dim3((std::max(1, node_cap) + 255) / 256), block, 0, s, keys, ids, pos, d_count, delta, base,
-                       incl, width, nodes, node_cap, order, out_info, want_hot);
-    return 0;
+    if (tree_sort_keys(s, pos, d_count, n_upper, center, width, workspace, n_cap, out_info, work) != 0) return -1;
+    return tree_emit_sorted(s, pos, d_count, n_upper, width, workspace, n_cap, nodes, node_cap, order, out_info, want_hot, nullptr);
 }
 
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,

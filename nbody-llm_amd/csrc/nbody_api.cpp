@@ -7,6 +7,7 @@
 // with the host inside nbody_steps, the Barnes-Hut path must (the octree is built on the host).
 #include "nbody_handle.h"
 #include "nbody_f64.h"
+#include "nbody_let.h"
 
 #include <algorithm>
 #include <chrono>
@@ -920,6 +921,7 @@ void free_all(NbodyHandle* h) {
     for (auto& ev : h->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->tree.clear();
     nbody64::destroy(h);
+    nbody::let::destroy(h);
     void* dev[] = {h->sh.pos_all, h->sh.vel, h->sh.acc, h->sh.seg_count, h->sh.escaped, h->sh.keep, h->sh.tile_state, h->sh.epoch, h->sh.inter, h->d_poison, h->d_aos,
                    h->d_nodes, h->d_order, h->d_split, h->d_walk_planes, h->d_walk, h->d_unified, h->d_hot, h->d_hot_info, h->d_bfs, h->d_bfs_ws, h->d_tree_ws, h->d_tree_cat, h->d_nested_stack, h->d_tree_info, h->d_counters, h->d_energy, h->d_sym_bounds, h->d_planes, h->d_cross_slices, h->d_xplanes, h->d_send};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -931,7 +933,14 @@ void free_all(NbodyHandle* h) {
 
 int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (!cfg || !out) return fail(nullptr, NBODY_ERR_INVALID, "null argument");
+    // ABI versions <= 2 end before shard_mode (48 bytes): such a caller gets index-block shards
+    constexpr uint32_t kOldConfigSize = 48;
+    NbodyConfig full{};
+    if (cfg->struct_size == kOldConfigSize) { std::memcpy(&full, cfg, kOldConfigSize); full.struct_size = sizeof(NbodyConfig); cfg = &full; }
     if (cfg->struct_size != sizeof(NbodyConfig)) return fail(nullptr, NBODY_ERR_INVALID, "NbodyConfig.struct_size mismatch");
+    if (cfg->shard_mode != NBODY_SHARD_INDEX && cfg->shard_mode != NBODY_SHARD_SPATIAL) return fail(nullptr, NBODY_ERR_INVALID, "unknown shard_mode");
+    if (cfg->shard_mode == NBODY_SHARD_SPATIAL && (cfg->method != NBODY_BARNES_HUT || cfg->math_mode != NBODY_MATH_FAST || cfg->dtype != NBODY_F32))
+        return fail(nullptr, NBODY_ERR_INVALID, "NBODY_SHARD_SPATIAL is the fast-math f32 Barnes-Hut path (halo exchange over the device-built tree)");
     if (cfg->method != NBODY_BRUTE_FORCE && cfg->method != NBODY_BARNES_HUT) return fail(nullptr, NBODY_ERR_INVALID, "unknown method");
     if (cfg->math_mode != NBODY_MATH_STRICT && cfg->math_mode != NBODY_MATH_FAST) return fail(nullptr, NBODY_ERR_INVALID, "unknown math_mode");
     if (cfg->leaf_mode != NBODY_LEAF_REFERENCE && cfg->leaf_mode != NBODY_LEAF_DIRECT) return fail(nullptr, NBODY_ERR_INVALID, "unknown leaf_mode");
@@ -957,6 +966,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (h->cfg.tree_build == NBODY_TREE_AUTO)   // the bit-exact path keeps the reference's (host) build
         h->cfg.tree_build = cfg->math_mode == NBODY_MATH_FAST ? NBODY_TREE_DEVICE : NBODY_TREE_HOST;
     if (h->cfg.dtype == NBODY_F64) { h->cfg.tree_build = NBODY_TREE_HOST; h->cfg.math_mode = NBODY_MATH_STRICT; }   // what F = f64 runs
+    if (h->cfg.shard_mode == NBODY_SHARD_SPATIAL) h->cfg.tree_build = NBODY_TREE_DEVICE;
     cfg = &h->cfg;
     h->device = dev;
     *out = nullptr;
@@ -988,6 +998,12 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     sh.n_seg = cfg->world_size;
     sh.my_seg = cfg->rank;
     sh.seg_cap = int((cfg->capacity + cfg->world_size - 1) / cfg->world_size);
+    const bool spatial = cfg->shard_mode == NBODY_SHARD_SPATIAL;
+    if (spatial) {   // a spatial handle holds its own bodies only (no gathered positions): one segment, with room for immigrants
+        sh.n_seg = 1;
+        sh.my_seg = 0;
+        if (cfg->world_size > 1) sh.seg_cap = int(std::min<uint64_t>(cfg->capacity, 2 * uint64_t(sh.seg_cap) + 64));
+    }
     const size_t cap = size_t(sh.seg_cap);
     CREATE_TRY(hipMalloc(&sh.pos_all, size_t(sh.n_seg) * cap * sizeof(float4)));
     CREATE_TRY(hipMalloc(&sh.vel, cap * sizeof(float4)));
@@ -1034,8 +1050,12 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     {
         const char* v = std::getenv("NBODY_BH_ASYNC");
         h->async_bh = cfg->method == NBODY_BARNES_HUT && cfg->tree_build == NBODY_TREE_DEVICE && cfg->world_size == 1 &&
-                      !(v && v[0] == '0');
+                      !spatial && !(v && v[0] == '0');
         if (h->async_bh) sh.poison = h->d_poison;
+    }
+    if (spatial) {
+        int rc_let = nbody::let::create(h);
+        if (rc_let) return bail(rc_let);
     }
     if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
     if (const char* v = std::getenv("NBODY_CROSS_SYM")) nbody_cross_sym = std::atoi(v);
@@ -1071,6 +1091,7 @@ void nbody_destroy(NbodyHandle* h) { free_all(h); }
 int nbody_clone(const NbodyHandle* src, NbodyHandle** out) {
     if (!src || !out) return fail(nullptr, NBODY_ERR_INVALID, "null argument");
     NbodyHandle* s = const_cast<NbodyHandle*>(src);
+    if (src->let) return fail(nullptr, NBODY_ERR_INVALID, "nbody_clone is not supported on NBODY_SHARD_SPATIAL handles");
     int rc = use_device(s);
     if (rc) return rc;
     rc = resolve_async(s);
@@ -1119,6 +1140,7 @@ int nbody_upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return (n && !aos) ? NBODY_ERR_INVALID : nbody64::upload(h, aos, n, stride);
+    if (h->let) return nbody::let::upload(h, aos, n, stride);
     rc = resolve_async(h);
     if (rc) return rc;
     Shard& sh = h->sh;
@@ -1187,6 +1209,7 @@ int nbody_count_global(NbodyHandle* h, size_t* n_out) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::count(h, n_out);
+    if (h->let) return nbody::let::count_global(h, n_out);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1197,7 +1220,7 @@ int nbody_count_global(NbodyHandle* h, size_t* n_out) {
 
 int nbody_add_point(NbodyHandle* h, const void* particle) {
     if (!h || !particle) return NBODY_ERR_INVALID;
-    if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "add_point is only supported on single-GPU handles");
+    if (h->sh.n_seg != 1 || h->let) return fail(h, NBODY_ERR_INVALID, "add_point is only supported on single-GPU handles");
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::add_point(h, particle);
@@ -1220,7 +1243,7 @@ int nbody_add_point(NbodyHandle* h, const void* particle) {
 
 int nbody_remove_point(NbodyHandle* h, size_t index) {
     if (!h) return NBODY_ERR_INVALID;
-    if (h->sh.n_seg != 1) return fail(h, NBODY_ERR_INVALID, "remove_point is only supported on single-GPU handles");
+    if (h->sh.n_seg != 1 || h->let) return fail(h, NBODY_ERR_INVALID, "remove_point is only supported on single-GPU handles");
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::remove_point(h, index);
@@ -1314,6 +1337,7 @@ int nbody_step_by(NbodyHandle* h, float dt) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::step_by(h, double(dt));
+    if (h->let) return nbody::let::step(h, dt);
     return step_impl(h, dt);
 }
 
@@ -1322,6 +1346,7 @@ int nbody_step_by_f64(NbodyHandle* h, double dt) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::step_by(h, dt);
+    if (h->let) return nbody::let::step(h, float(dt));
     return step_impl(h, float(dt));
 }
 
@@ -1330,6 +1355,10 @@ int nbody_steps(NbodyHandle* h, int k) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::steps(h, k);
+    if (h->let) {
+        for (int i = 0; i < k; ++i) { rc = nbody::let::step(h, h->dt); if (rc) return rc; }
+        return NBODY_OK;
+    }
     for (int i = 0; i < k; ++i) {
         rc = step_impl(h, h->dt);  // Simulation::step, shared.rs:86-88
         if (rc) return rc;
@@ -1342,6 +1371,7 @@ int nbody_update_forces(NbodyHandle* h) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::update_forces(h);
+    if (h->let) return h->bounds_set ? nbody::let::update_forces(h) : fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
     if (h->cfg.method == NBODY_BARNES_HUT && !h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
     rc = resolve_async(h);
     if (rc) return rc;
@@ -1532,6 +1562,38 @@ int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
     h->comm_ready = true;
     return NBODY_OK;
 }
+
+int nbody_download_ids(NbodyHandle* h, int32_t* ids, size_t cap, size_t* n_out) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->let) return fail(h, NBODY_ERR_INVALID, "nbody_download_ids is for NBODY_SHARD_SPATIAL handles (index-block shards: nbody_local_range)");
+    return nbody::let::download_ids(h, ids, cap, n_out);
+}
+
+int nbody_let_stats(NbodyHandle* h, NbodyLetStats* out) {
+    if (!h || !out) return NBODY_ERR_INVALID;
+    if (!h->let) return fail(h, NBODY_ERR_INVALID, "not an NBODY_SHARD_SPATIAL handle");
+    return nbody::let::stats(h, out);
+}
+
+int nbody_debug_let_phase(NbodyHandle* h, int phase, float dt) {
+    if (!h) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->let) return fail(h, NBODY_ERR_INVALID, "not an NBODY_SHARD_SPATIAL handle");
+    return nbody::let::debug_phase(h, phase, dt);
+}
+
+int nbody_debug_let_exchange(NbodyHandle* h, NbodyHandle* peer, int which) {
+    if (!h || !peer) return NBODY_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->let || !peer->let) return fail(h, NBODY_ERR_INVALID, "not an NBODY_SHARD_SPATIAL handle");
+    return nbody::let::debug_exchange(h, peer, which);
+}
+
+int nbody_debug_let_set_prune(NbodyHandle* h, int prune);   // (nbody_let.cpp owns the state)
 
 int nbody_local_range(const NbodyHandle* h, size_t* first, size_t* count) {
     if (!h) return NBODY_ERR_INVALID;

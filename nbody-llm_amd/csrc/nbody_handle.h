@@ -16,6 +16,7 @@ using nbody::BoundsF;
 using nbody::Shard;
 
 namespace nbody64 { struct State; }   // F = f64 handles (nbody_f64.cpp)
+namespace nbody { namespace let { struct State; } }   // spatial shards (nbody_let.cpp)
 
 struct NbodyHandle {
     NbodyConfig cfg{};
@@ -127,6 +128,7 @@ struct NbodyHandle {
     bool exchange_in_flight = false;
 
     nbody64::State* f64 = nullptr;   // NbodyConfig.dtype == NBODY_F64: the whole state lives here
+    nbody::let::State* let = nullptr; // NbodyConfig.shard_mode == NBODY_SHARD_SPATIAL: the halo-exchange machinery
 
     std::string err;
 };

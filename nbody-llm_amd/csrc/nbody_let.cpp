@@ -1,0 +1,542 @@
+// nbody_let.cpp -- host orchestration of Barnes-Hut over spatial shards with a halo exchange; see kernels_let.hip for
+// the scheme.  A spatial handle is a SINGLE-segment shard (its own bodies only): drift, retain, the device build's
+// kernels and the walk run on it as on a one-GPU handle; what is added are five phases separated by four exchanges:
+//   phase 0  drift, retain, pick the bodies whose key left the rank's range and pack them per destination
+//   --- exchange 0: migrants (fixed-size slots, all-to-all)
+//   phase 1  take the immigrants in, keys + sort of the own bodies, first/last key and bounding box
+//   --- exchange 1: all-gather of the 48-byte end infos
+//   phase 2  edge values, delta / scans / emit of the own slice, contributions to every earlier rank's spanning cells
+//   --- exchange 2: all-gather of the spanning-cell tables (13 KB per rank)
+//   phase 3  own slice into the global-index array, all spanning cells finished, the nodes each partner can reach
+//            flagged (ancestors against its bounding box) and packed
+//   --- exchange 3: node records, variable size (the counts travel first)
+//   phase 4  imports dropped at their global indices, walk, kick + half drift
+// Production (`step`) does the exchanges with RCCL on the handle's stream; the tests run G handles of one process on one
+// GPU and do them as device-to-device copies (debug_phase / debug_exchange) -- same kernels, same buffers.
+#include "nbody_let.h"
+#include "kernels_let.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+
+extern "C" int nbody_bh_walk_split;
+
+namespace nbody {
+namespace let {
+
+struct State {
+    int G = 1, me = 0;
+    int mig_cap = 4096;
+    bool prune = true;
+    std::vector<unsigned long long> h_bounds;   // [G + 1]
+    unsigned long long* d_bounds = nullptr;
+    Migrant *d_send_mig = nullptr, *d_recv_mig = nullptr;   // [G][mig_cap]
+    int *d_send_count = nullptr, *d_recv_count = nullptr;   // [G]
+    int* d_new_count = nullptr;
+    int* d_flags = nullptr;       // [2] sticky flags (also the walk's poison word), step counter
+    int* d_box_ord = nullptr;     // [6]
+    EndInfo* d_ends = nullptr;    // [G]
+    int* d_edge = nullptr;        // [3]
+    RoundB* d_rb = nullptr;       // [G]
+    int* d_offsets = nullptr;     // [G + 1]
+    int* d_top_index = nullptr;   // [G][kLevels]
+    int* d_split = nullptr;       // [4]: first[0] = 0, first[1] = total nodes, n_anc[0] = 0
+    float4* d_local = nullptr;    // own slice as the build emits it (local indices)
+    int local_cap = 0;            // nodes
+    float4* d_global = nullptr;   // the global-index node array
+    int global_cap = 0;
+    int* d_order = nullptr;
+    int* d_tree_info = nullptr;   // [4] of the local build
+    void* d_ws = nullptr;         // workspace of the build
+    size_t ws_cap = 0;
+    int* d_parent = nullptr;
+    unsigned char* d_depth = nullptr;
+    unsigned int* d_upper_ok = nullptr;   // [kLevels]
+    unsigned int* d_node_flags = nullptr;
+    int* d_let_count = nullptr;   // [G] nodes for each partner
+    int* d_let_cursor = nullptr;  // [G]
+    LetRecord* d_let_send = nullptr;      // [G][let_stride]
+    size_t let_stride = 0;
+    LetRecord* d_let_recv = nullptr;
+    size_t let_recv_cap = 0;
+    int* d_let_matrix = nullptr;  // [G][G] counts (all-gathered rows)
+    int* h_pin = nullptr;         // pinned scratch [G*G + 64]
+    TreeDevWork work;
+    NbodyLetStats st{};
+    size_t n_at_upload = 0;
+    std::vector<int> recv_n;      // emulation / production: records received from each rank this pass
+};
+
+namespace {
+
+int fail(NbodyHandle* h, int code, const std::string& msg) { h->err = msg; return code; }
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, NBODY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+#define NCCL_TRY(h, expr)                                                                             \
+    do {                                                                                              \
+        ncclResult_t r_ = (expr);                                                                     \
+        if (r_ != ncclSuccess)                                                                        \
+            return fail(h, NBODY_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));       \
+    } while (0)
+
+unsigned long long host_key(const float* p, const float c[3], float width) {   // kernels_tree.hip k_tree_keys on the host
+    float cx = c[0], cy = c[1], cz = c[2];
+    float hw = width * 0.5f;
+    unsigned long long key = 0;
+    for (int l = 0; l < kLevels; ++l) {
+        const bool bx = p[0] > cx, by = p[1] > cy, bz = p[2] > cz;
+        key = (key << 3) | (unsigned long long)((bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0));
+        hw = hw * 0.5f;
+        cx = bx ? cx + hw : cx - hw;
+        cy = by ? cy + hw : cy - hw;
+        cz = bz ? cz + hw : cz - hw;
+    }
+    return key;
+}
+
+template <class T> int dev_alloc(NbodyHandle* h, T** p, size_t n) {
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(1, n) * sizeof(T)));
+    HIP_TRY(h, hipMemsetAsync(*p, 0, std::max<size_t>(1, n) * sizeof(T), h->stream));
+    return NBODY_OK;
+}
+
+int ensure_node_buffers(NbodyHandle* h, State& s) {
+    const Shard& sh = h->sh;
+    const int want_local = 4 * sh.seg_cap + 64;
+    if (s.local_cap < want_local) {
+        for (void* p : {(void*)s.d_local, (void*)s.d_parent, (void*)s.d_depth, (void*)s.d_node_flags, (void*)s.d_let_send})
+            if (p) (void)hipFree(p);
+        s.d_local = nullptr; s.d_parent = nullptr; s.d_depth = nullptr; s.d_node_flags = nullptr; s.d_let_send = nullptr;
+        int rc;
+        if ((rc = dev_alloc(h, &s.d_local, size_t(want_local) * 2))) return rc;
+        if ((rc = dev_alloc(h, &s.d_parent, size_t(want_local)))) return rc;
+        if ((rc = dev_alloc(h, &s.d_depth, size_t(want_local)))) return rc;
+        if ((rc = dev_alloc(h, &s.d_node_flags, size_t(want_local)))) return rc;
+        s.let_stride = size_t(want_local);
+        if ((rc = dev_alloc(h, &s.d_let_send, s.let_stride * size_t(s.G)))) return rc;
+        s.local_cap = want_local;
+    }
+    const long long want_global = 4LL * (long long)h->cfg.capacity + 64LL * s.G + 64;
+    if (s.global_cap < want_global) {
+        if (s.d_global) (void)hipFree(s.d_global);
+        s.d_global = nullptr;
+        int rc;
+        if ((rc = dev_alloc(h, &s.d_global, size_t(want_global) * 2))) return rc;
+        s.global_cap = int(std::min<long long>(want_global, 0x7fffffff));
+    }
+    if (s.ws_cap < size_t(sh.seg_cap)) {
+        if (s.d_ws) (void)hipFree(s.d_ws);
+        if (s.d_order) (void)hipFree(s.d_order);
+        s.d_ws = nullptr; s.d_order = nullptr;
+        HIP_TRY(h, hipMalloc(&s.d_ws, tree_build_workspace_bytes(size_t(sh.seg_cap))));
+        int rc;
+        if ((rc = dev_alloc(h, &s.d_order, size_t(sh.seg_cap)))) return rc;
+        s.ws_cap = size_t(sh.seg_cap);
+    }
+    return NBODY_OK;
+}
+
+// ---- the phases (everything is enqueued on h->stream; nothing here waits for the device)
+int phase0(NbodyHandle* h, State& s, float dt, bool drift) {
+    Shard& sh = h->sh;
+    int rc = ensure_node_buffers(h, s);
+    if (rc) return rc;
+    if (drift) {
+        if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+        launch_drift_half(h->stream, sh, int(h->n_local), dt, h->bnd);   // integrate_pre_force
+        launch_compact(h->stream, sh, int(h->n_local));                  // retain
+    }
+    launch_classify(h->stream, sh, int(h->n_local), h->center, h->width, s.d_bounds, s.G, s.me, s.d_send_mig, s.d_send_count, s.mig_cap,
+                    s.d_flags);
+    launch_compact(h->stream, sh, int(h->n_local));                      // the emigrants leave
+    h->count_dirty = true;
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+int phase1(NbodyHandle* h, State& s) {
+    Shard& sh = h->sh;
+    launch_append(h->stream, sh, s.d_recv_mig, s.d_recv_count, s.G, s.mig_cap, s.d_flags, s.d_new_count, s.d_send_count);
+    // the host's bound of the own count: everything that could have arrived
+    h->n_local = std::min<size_t>(size_t(sh.seg_cap), h->n_local + size_t(s.G) * size_t(s.mig_cap));
+    if (tree_sort_keys(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->center, h->width, s.d_ws, s.ws_cap, s.d_tree_info, &s.work) != 0)
+        return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
+    launch_ends(h->stream, sh, int(h->n_local), s.work.keys, s.d_box_ord, s.d_ends + s.me);
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+int phase2(NbodyHandle* h, State& s) {
+    Shard& sh = h->sh;
+    launch_edges(h->stream, s.d_ends, s.G, s.me, s.d_edge);
+    if (tree_emit_sorted(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->width, s.d_ws, s.ws_cap, s.d_local, s.local_cap, s.d_order,
+                         s.d_tree_info, 0, s.d_edge) != 0)
+        return fail(h, NBODY_ERR_HIP, "device octree build failed");
+    launch_contrib(h->stream, sh, s.work, s.d_tree_info, s.d_ends, s.d_edge, s.G, s.me, s.d_rb + s.me);
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+int phase3(NbodyHandle* h, State& s) {
+    Shard& sh = h->sh;
+    HIP_TRY(h, hipMemsetAsync(s.d_let_count, 0, sizeof(int) * s.G, h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d_let_cursor, 0, sizeof(int) * s.G, h->stream));
+    launch_finalize(h->stream, s.d_local, s.local_cap, s.d_tree_info, s.d_rb, s.d_ends, s.G, s.me, h->width, s.d_global, s.global_cap, s.d_offsets,
+                    s.d_top_index, s.d_flags);
+    launch_flags_and_pack(h->stream, sh, s.work, s.local_cap, s.d_tree_info, s.d_edge, s.d_global, s.d_offsets, s.d_top_index, s.d_ends, s.G, s.me,
+                          h->theta2, s.d_parent, s.d_depth, s.d_upper_ok, s.d_node_flags, s.d_let_count, s.d_let_send, s.let_stride,
+                          s.d_let_cursor, s.prune);
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
+// the walk over the assembled array (+ kick + half drift when this is a step)
+struct SplitInit { int first0, first1, n_anc0, pad; };
+int phase4(NbodyHandle* h, State& s, float dt, bool kick) {
+    Shard& sh = h->sh;
+    // first[] of the unsplit walk: {0, total}; the total lives on the device (offsets[G])
+    HIP_TRY(h, hipMemsetAsync(s.d_split, 0, 4 * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.d_split + 1, s.d_offsets + s.G, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    TreeDev td;
+    td.nodes = s.d_global; td.n_nodes = s.global_cap;
+    td.order = s.d_order; td.n_order = int(h->n_local);
+    td.n_order_dev = sh.own_count();
+    td.poison = s.d_flags;
+    td.n_split = 1;
+    td.split_first = s.d_split;
+    td.split_n_anc = s.d_split + 2;
+    td.split_anc = s.d_split + 2;
+    {
+        int kicked = 0;
+        launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2, 1, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT,
+                       nullptr, &kicked);
+    }
+    if (kick) {
+        launch_kick_drift(h->stream, sh, int(h->n_local), dt);   // integrate_after_force
+        h->elapsed += dt;
+        h->stats.steps += 1;
+    }
+    HIP_TRY(h, hipGetLastError());
+    s.st.steps += 1;
+    return NBODY_OK;
+}
+
+}  // namespace
+
+int create(NbodyHandle* h) {
+    State* sp = new State();
+    h->let = sp;
+    State& s = *sp;
+    s.G = h->cfg.world_size;
+    s.me = h->cfg.rank;
+    if (s.G > kMaxRanks) return fail(h, NBODY_ERR_INVALID, "NBODY_SHARD_SPATIAL supports up to 16 ranks");
+    if (const char* v = std::getenv("NBODY_LET_MIG_CAP")) s.mig_cap = std::max(16, std::atoi(v));
+    s.recv_n.assign(s.G, 0);
+    int rc;
+    if ((rc = dev_alloc(h, &s.d_bounds, size_t(s.G) + 1))) return rc;
+    if ((rc = dev_alloc(h, &s.d_send_mig, size_t(s.G) * s.mig_cap))) return rc;
+    if ((rc = dev_alloc(h, &s.d_recv_mig, size_t(s.G) * s.mig_cap))) return rc;
+    if ((rc = dev_alloc(h, &s.d_send_count, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_recv_count, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_new_count, 1))) return rc;
+    if ((rc = dev_alloc(h, &s.d_flags, 2))) return rc;
+    if ((rc = dev_alloc(h, &s.d_box_ord, 6))) return rc;
+    {
+        int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, int(0x80000000), int(0x80000000), int(0x80000000)};
+        HIP_TRY(h, hipMemcpyAsync(s.d_box_ord, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if ((rc = dev_alloc(h, &s.d_ends, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_edge, 4))) return rc;
+    if ((rc = dev_alloc(h, &s.d_rb, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_offsets, size_t(s.G) + 1))) return rc;
+    if ((rc = dev_alloc(h, &s.d_top_index, size_t(s.G) * kLevels))) return rc;
+    if ((rc = dev_alloc(h, &s.d_split, 4))) return rc;
+    if ((rc = dev_alloc(h, &s.d_tree_info, 4))) return rc;
+    if ((rc = dev_alloc(h, &s.d_upper_ok, kLevels))) return rc;
+    if ((rc = dev_alloc(h, &s.d_let_count, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_let_cursor, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_let_matrix, size_t(s.G) * s.G))) return rc;
+    if ((rc = dev_alloc(h, &h->sh.ids, size_t(h->sh.seg_cap)))) return rc;
+    HIP_TRY(h, hipHostMalloc(&s.h_pin, (size_t(s.G) * s.G + 64) * sizeof(int), hipHostMallocDefault));
+    h->sh.poison = s.d_flags;   // a raised flag stops every kernel that would change the state
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+
+void destroy(NbodyHandle* h) {
+    State* s = h->let;
+    if (!s) return;
+    void* dev[] = {s->d_bounds, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_recv_count, s->d_new_count, s->d_flags, s->d_box_ord,
+                   s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_local, s->d_global, s->d_order, s->d_tree_info,
+                   s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_cursor, s->d_let_send,
+                   s->d_let_recv, s->d_let_matrix, h->sh.ids};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    h->sh.ids = nullptr;
+    h->sh.poison = nullptr;
+    if (s->h_pin) (void)hipHostFree(s->h_pin);
+    delete s;
+    h->let = nullptr;
+}
+
+// Every rank passes the same full vector.  Bounds = the G-quantiles of the keys; this rank keeps the bodies of its range.
+int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
+    State& s = *h->let;
+    Shard& sh = h->sh;
+    if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "NBODY_SHARD_SPATIAL: nbody_set_bounds must come before nbody_upload (the shards are key ranges of the root box)");
+    const char* src = static_cast<const char*>(aos);
+    std::vector<unsigned long long> key(n);
+    std::vector<uint32_t> idx(n);
+    for (size_t k = 0; k < n; ++k) {
+        float p[3];
+        std::memcpy(p, src + k * stride, 12);
+        key[k] = host_key(p, h->center, h->width);
+        idx[k] = uint32_t(k);
+    }
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+    s.h_bounds.assign(size_t(s.G) + 1, 0ull);
+    for (int r = 1; r < s.G; ++r) s.h_bounds[r] = n ? key[idx[std::min(n - 1, size_t(r) * n / size_t(s.G))]] : 0ull;
+    for (int r = 1; r < s.G; ++r) s.h_bounds[r] = std::max(s.h_bounds[r], s.h_bounds[r - 1]);
+    s.h_bounds[s.G] = 1ull << 63;
+    HIP_TRY(h, hipMemcpyAsync(s.d_bounds, s.h_bounds.data(), (size_t(s.G) + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+    // own bodies, in the vector's order
+    std::vector<int> own;
+    for (size_t k = 0; k < n; ++k) {
+        int dest = 0;
+        for (int r = 1; r < s.G; ++r) if (s.h_bounds[r] <= key[k]) dest = r;
+        if (dest == s.me) own.push_back(int(k));
+    }
+    if (own.size() > size_t(sh.seg_cap)) return fail(h, NBODY_ERR_CAPACITY, "NBODY_SHARD_SPATIAL: this rank's key range holds more bodies than its capacity");
+    const size_t m = own.size();
+    // staging through the handle's AoS buffers (40-byte records)
+    if (m > h->aos_cap) {
+        if (h->d_aos) (void)hipFree(h->d_aos);
+        if (h->h_aos) (void)hipHostFree(h->h_aos);
+        h->d_aos = nullptr; h->h_aos = nullptr; h->aos_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_aos, std::max<size_t>(1, m) * 40));
+        HIP_TRY(h, hipHostMalloc(&h->h_aos, std::max<size_t>(1, m) * 40, hipHostMallocDefault));
+        h->aos_cap = std::max<size_t>(1, m);
+    }
+    for (size_t j = 0; j < m; ++j) std::memcpy(h->h_aos + 10 * j, src + size_t(own[j]) * stride, 40);
+    if (m) HIP_TRY(h, hipMemcpyAsync(h->d_aos, h->h_aos, m * 40, hipMemcpyHostToDevice, h->stream));
+    launch_aos_to_soa(h->stream, h->d_aos, 10, int(m), sh.own_pos(), sh.vel, sh.acc);
+    if (m) HIP_TRY(h, hipMemcpyAsync(sh.ids, own.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(sh.escaped, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d_send_count, 0, sizeof(int) * s.G, h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d_recv_count, 0, sizeof(int) * s.G, h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d_flags, 0, 2 * sizeof(int), h->stream));
+    h->n_local = m;
+    h->seg_count_host[0] = int(m);
+    h->h_counts[0] = int(m);
+    HIP_TRY(h, hipMemcpyAsync(sh.seg_count, h->h_counts, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // own[] and the staging are reused
+    h->count_dirty = false;
+    h->first_global = 0; h->n_at_upload = m;
+    s.n_at_upload = n;
+    return NBODY_OK;
+}
+
+int download_ids(NbodyHandle* h, int32_t* ids, size_t cap, size_t* n_out) {
+    Shard& sh = h->sh;
+    HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t n = size_t(h->h_counts[0]);
+    h->n_local = n; h->seg_count_host[0] = int(n); h->count_dirty = false;
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "download buffer too small");
+    if (n && ids) {
+        HIP_TRY(h, hipMemcpy(ids, sh.ids, n * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return NBODY_OK;
+}
+
+int check_flags(NbodyHandle* h) {
+    State& s = *h->let;
+    HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int f = s.h_pin[0];
+    if (!f) return NBODY_OK;
+    if (f & (kFlagDeep)) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 21 levels");
+    if (f & kFlagMigOverflow) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: more bodies migrate to one rank in a step than NBODY_LET_MIG_CAP");
+    if (f & kFlagCapacity) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: a rank's capacity is exhausted by immigrants");
+    if (f & (kFlagNodeCap | kFlagNodeCapLocal)) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: node array too small");
+    return fail(h, NBODY_ERR_INVALID, "spatial shards: the device raised flag " + std::to_string(f));
+}
+
+int count_global(NbodyHandle* h, size_t* n_out) {
+    State& s = *h->let;
+    std::vector<EndInfo> e(size_t(s.G));
+    HIP_TRY(h, hipMemcpy(e.data(), s.d_ends, sizeof(EndInfo) * s.G, hipMemcpyDeviceToHost));
+    size_t t = 0;
+    for (const EndInfo& x : e) t += size_t(std::max(0, x.n_bodies));
+    *n_out = t;
+    return NBODY_OK;
+}
+
+int stats(NbodyHandle* h, NbodyLetStats* out) {
+    *out = h->let->st;
+    return NBODY_OK;
+}
+
+// bookkeeping after a pass: read the small numbers back (the pass is over: the caller synchronises anyway)
+static int account(NbodyHandle* h, State& s) {
+    HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_let_count, sizeof(int) * s.G, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_pin + 16, s.d_offsets, sizeof(int) * (s.G + 1), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_pin + 40, s.d_tree_info, sizeof(int) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    uint64_t sent = 0;
+    for (int r = 0; r < s.G; ++r) sent += uint64_t(std::max(0, s.h_pin[r]));
+    s.st.nodes_sent += sent;
+    s.st.nodes_local += uint64_t(std::max(0, s.h_pin[40]));
+    s.st.nodes_global += uint64_t(std::max(0, s.h_pin[16 + s.G]));
+    h->stats.tree_nodes = uint64_t(std::max(0, s.h_pin[16 + s.G]));
+    h->n_local = size_t(std::max(0, s.h_pin[42]));   // the live own count (bodies in the local build)
+    h->seg_count_host[0] = int(h->n_local);
+    h->count_dirty = false;
+    const uint64_t partners = uint64_t(std::max(0, s.G - 1));
+    s.st.bytes_sent += sent * sizeof(LetRecord) + partners * (uint64_t(s.mig_cap) * sizeof(Migrant) + sizeof(EndInfo) + sizeof(RoundB));
+    s.st.bytes_allgather_equivalent += partners * uint64_t(std::max(0, s.h_pin[42])) * 16ull;
+    uint64_t rec = 0;
+    for (int n : s.recv_n) rec += uint64_t(n);
+    s.st.nodes_received += rec;
+    return NBODY_OK;
+}
+
+// ---- production: the exchanges with RCCL
+static int pass(NbodyHandle* h, float dt, bool is_step) {
+    State& s = *h->let;
+    if (s.G > 1 && !h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    int rc = phase0(h, s, dt, is_step);
+    if (rc) return rc;
+    if (s.G > 1) {   // exchange 0: slot r of my send buffer -> rank r; its slot for me <- rank r
+        NCCL_TRY(h, ncclGroupStart());
+        for (int r = 0; r < s.G; ++r) {
+            if (r == s.me) continue;
+            NCCL_TRY(h, ncclSend(s.d_send_mig + size_t(r) * s.mig_cap, size_t(s.mig_cap) * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
+            NCCL_TRY(h, ncclRecv(s.d_recv_mig + size_t(r) * s.mig_cap, size_t(s.mig_cap) * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
+            NCCL_TRY(h, ncclSend(s.d_send_count + r, 1, ncclInt32, r, h->comm, h->stream));
+            NCCL_TRY(h, ncclRecv(s.d_recv_count + r, 1, ncclInt32, r, h->comm, h->stream));
+        }
+        NCCL_TRY(h, ncclGroupEnd());
+    }
+    rc = phase1(h, s);
+    if (rc) return rc;
+    if (s.G > 1) NCCL_TRY(h, ncclAllGather(s.d_ends + s.me, s.d_ends, sizeof(EndInfo), ncclChar, h->comm, h->stream));   // exchange 1
+    rc = phase2(h, s);
+    if (rc) return rc;
+    if (s.G > 1) NCCL_TRY(h, ncclAllGather(s.d_rb + s.me, s.d_rb, sizeof(RoundB), ncclChar, h->comm, h->stream));         // exchange 2
+    rc = phase3(h, s);
+    if (rc) return rc;
+    std::fill(s.recv_n.begin(), s.recv_n.end(), 0);
+    if (s.G > 1) {   // exchange 3: the counts first (row r of the matrix = what rank r sends to everybody), then the records
+        NCCL_TRY(h, ncclAllGather(s.d_let_count, s.d_let_matrix, size_t(s.G), ncclInt32, h->comm, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_let_matrix, sizeof(int) * s.G * s.G, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        size_t total_in = 0;
+        for (int r = 0; r < s.G; ++r) { s.recv_n[r] = r == s.me ? 0 : s.h_pin[r * s.G + s.me]; total_in += size_t(s.recv_n[r]); }
+        if (total_in > s.let_recv_cap) {
+            if (s.d_let_recv) (void)hipFree(s.d_let_recv);
+            s.d_let_recv = nullptr; s.let_recv_cap = 0;
+            HIP_TRY(h, hipMalloc(&s.d_let_recv, (total_in + total_in / 4 + 1024) * sizeof(LetRecord)));
+            s.let_recv_cap = total_in + total_in / 4 + 1024;
+        }
+        NCCL_TRY(h, ncclGroupStart());
+        size_t at = 0;
+        for (int r = 0; r < s.G; ++r) {
+            if (r == s.me) continue;
+            const int out = std::min<long long>(s.h_pin[s.me * s.G + r], (long long)s.let_stride);
+            if (out > 0) NCCL_TRY(h, ncclSend(s.d_let_send + size_t(r) * s.let_stride, size_t(out) * sizeof(LetRecord), ncclChar, r, h->comm, h->stream));
+            if (s.recv_n[r] > 0) NCCL_TRY(h, ncclRecv(s.d_let_recv + at, size_t(s.recv_n[r]) * sizeof(LetRecord), ncclChar, r, h->comm, h->stream));
+            at += size_t(s.recv_n[r]);
+        }
+        NCCL_TRY(h, ncclGroupEnd());
+        launch_scatter(h->stream, s.d_let_recv, int(total_in), s.d_global, s.global_cap);
+    }
+    rc = phase4(h, s, dt, is_step);
+    if (rc) return rc;
+    return account(h, s);
+}
+
+int step(NbodyHandle* h, float dt) {
+    int rc = pass(h, dt, true);
+    if (rc) return rc;
+    return check_flags(h);
+}
+
+int update_forces(NbodyHandle* h) {
+    int rc = pass(h, 0.f, false);
+    if (rc) return rc;
+    return check_flags(h);
+}
+
+// ---- one-process emulation: phases and exchanges driven from outside
+int debug_phase(NbodyHandle* h, int phase, float dt) {
+    State& s = *h->let;
+    switch (phase) {
+        case 0: return phase0(h, s, dt, true);
+        case 10: return phase0(h, s, dt, false);   // the same for a force pass outside a step (no drift)
+        case 1: return phase1(h, s);
+        case 2: return phase2(h, s);
+        case 3: { std::fill(s.recv_n.begin(), s.recv_n.end(), 0); return phase3(h, s); }
+        case 4: { int rc = phase4(h, s, dt, true); if (rc) return rc; rc = account(h, s); return rc ? rc : check_flags(h); }
+        case 14: { int rc = phase4(h, s, dt, false); if (rc) return rc; rc = account(h, s); return rc ? rc : check_flags(h); }
+        default: return fail(h, NBODY_ERR_INVALID, "unknown phase");
+    }
+}
+
+int debug_exchange(NbodyHandle* h, NbodyHandle* peer, int which) {
+    State& s = *h->let;
+    State& p = *peer->let;
+    const int me = s.me, pr = p.me;
+    HIP_TRY(h, hipStreamSynchronize(peer->stream));
+    switch (which) {
+        case 0:   // migrants: the peer's slot for me
+            HIP_TRY(h, hipMemcpyAsync(s.d_recv_mig + size_t(pr) * s.mig_cap, p.d_send_mig + size_t(me) * p.mig_cap, size_t(s.mig_cap) * sizeof(Migrant),
+                                      hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(s.d_recv_count + pr, p.d_send_count + me, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+            break;
+        case 1:
+            HIP_TRY(h, hipMemcpyAsync(s.d_ends + pr, p.d_ends + pr, sizeof(EndInfo), hipMemcpyDeviceToDevice, h->stream));
+            break;
+        case 2:
+            HIP_TRY(h, hipMemcpyAsync(s.d_rb + pr, p.d_rb + pr, sizeof(RoundB), hipMemcpyDeviceToDevice, h->stream));
+            break;
+        case 3: {
+            int n = 0;
+            HIP_TRY(h, hipMemcpy(&n, p.d_let_count + me, sizeof(int), hipMemcpyDeviceToHost));
+            if (size_t(n) > p.let_stride) return fail(h, NBODY_ERR_CAPACITY, "export list overflow");
+            if (size_t(n) > s.let_recv_cap) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                if (s.d_let_recv) (void)hipFree(s.d_let_recv);
+                s.d_let_recv = nullptr; s.let_recv_cap = 0;
+                HIP_TRY(h, hipMalloc(&s.d_let_recv, (size_t(n) + size_t(n) / 4 + 1024) * sizeof(LetRecord)));
+                s.let_recv_cap = size_t(n) + size_t(n) / 4 + 1024;
+            }
+            if (n > 0) {
+                HIP_TRY(h, hipMemcpyAsync(s.d_let_recv, p.d_let_send + size_t(me) * p.let_stride, size_t(n) * sizeof(LetRecord), hipMemcpyDeviceToDevice, h->stream));
+                launch_scatter(h->stream, s.d_let_recv, n, s.d_global, s.global_cap);
+            }
+            s.recv_n[pr] = n;
+            break;
+        }
+        default: return fail(h, NBODY_ERR_INVALID, "unknown exchange");
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+
+}  // namespace let
+}  // namespace nbody
+
+extern "C" int nbody_debug_let_set_prune(NbodyHandle* h, int prune) {
+    if (!h || !h->let) return NBODY_ERR_INVALID;
+    h->let->prune = prune != 0;
+    return NBODY_OK;
+}

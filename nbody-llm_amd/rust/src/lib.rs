@@ -37,6 +37,8 @@ struct NbodyConfig {
     capacity: u64,
     tree_build: i32,
     dtype: i32,
+    shard_mode: i32, // NBODY_SHARD_INDEX (0); NBODY_SHARD_SPATIAL (1) is the multi-GPU halo-exchange mode
+    reserved: i32,
 }
 
 #[repr(C)]
@@ -215,6 +217,8 @@ impl<F: HipFloat, const METHOD: i32> HipSimulation<F, METHOD> {
             capacity: if o.capacity > 0 { o.capacity as u64 } else { (points.len().max(1) * 2) as u64 }, // headroom for add_point
             tree_build: o.tree_build as i32,
             dtype: F::DTYPE,
+            shard_mode: 0,
+            reserved: 0,
         };
         let mut h: *mut NbodyHandle = std::ptr::null_mut();
         let rc = unsafe { nbody_create(&cfg, &mut h) };

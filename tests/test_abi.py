@@ -24,12 +24,14 @@ def test_library_exports_every_declared_symbol(nb):
     lib = ctypes.CDLL(nb.LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"libnbody_hip.so lacks {missing}"
-    assert lib.nbody_abi_version() == 2
+    assert lib.nbody_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(nb):
-    # uint32 + 7 x int32 + uint64 + 2 x int32; 6 x uint64 + 4 x double
-    assert ctypes.sizeof(nb.NbodyConfig) == 48
+    # uint32 + 7 x int32 + uint64 + 4 x int32 (48 bytes up to ABI 2, then shard_mode + reserved); 6 x uint64 + 4 x double
+    assert ctypes.sizeof(nb.NbodyConfig) == 56
+    assert ctypes.sizeof(nb.NbodyLetStats) == 64
+    assert nb.PARTICLE_DTYPE64.itemsize == 80
     assert ctypes.sizeof(nb.NbodyStats) == 80
     assert nb.PARTICLE_DTYPE.itemsize == 40
     assert [nb.PARTICLE_DTYPE.fields[k][1] for k in ("position", "velocity", "acceleration", "mass")] == [0, 12, 24, 36]
