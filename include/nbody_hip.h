@@ -59,7 +59,7 @@ enum { NBODY_MATH_STRICT = 0, /* sqrt, (d*d)*d, g/r^3, no FMA contraction, partn
 enum { NBODY_TREE_HOST = 0,    /* host, every step (north_star; barnes_hut.rs:143-183 bit for bit) */
        NBODY_TREE_DEVICE = 1,  /* device: same cells and links, centre-of-mass
                                   sums in a different order (f64 prefix sums), so node counts may differ
-                                  by a few parts in 1e4; <= 21 levels (a deeper step is built on the host).
+                                  by a few parts in 1e4; <= 42 levels (a deeper step is built on the host).
                                   Single-shard handles enqueue their steps without any read-back */
        NBODY_TREE_AUTO = 2 };  /* NBODY_MATH_FAST -> device, NBODY_MATH_STRICT -> host (the bit-exact path);
                                   what the host-side mirrors pass by default */
@@ -203,6 +203,9 @@ typedef struct NbodyLetStats {
     uint64_t nodes_received;    /* node records it imported */
     uint64_t bytes_sent;        /* bytes of all four exchanges this rank sent (migrants, end info, spanning-cell tables, nodes) */
     uint64_t bytes_allgather_equivalent; /* what the index-block scheme sends per rank for the same passes: 16 B per own body */
+    double phase_ms[5];         /* device time of the five phases between the exchanges, summed over the passes made with
+                                 * nbody_set_profiling(h, 1): drift + retain + pick migrants | take them in, keys, sort |
+                                 * emit the slice + spanning-cell table | finish + flag + pack the export | walk + kick */
 } NbodyLetStats;
 int nbody_let_stats(NbodyHandle* h, NbodyLetStats* out);
 

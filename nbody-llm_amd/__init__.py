@@ -81,7 +81,7 @@ class NbodyConfig(C.Structure):
 
 class NbodyLetStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("steps", "bodies_migrated", "nodes_local", "nodes_global", "nodes_sent", "nodes_received",
-                                          "bytes_sent", "bytes_allgather_equivalent")]
+                                          "bytes_sent", "bytes_allgather_equivalent")] + [("phase_ms", C.c_double * 5)]
 
 
 class NbodyStats(C.Structure):

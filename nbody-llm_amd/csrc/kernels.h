@@ -137,6 +137,7 @@ struct TreeDevWork {  // arrays of the last build (inside its workspace)
     const signed char* delta = nullptr;         // levels shared by neighbouring sorted bodies
     const int* base = nullptr;                  // first node of every sorted body
     const int* ids = nullptr;                   // sorted position -> body
+    const unsigned long long* keys2 = nullptr;  // levels 21..41, defined inside groups of equal keys only
     const void* incl = nullptr;                 // inclusive f64 prefix sums {m, m x, m y, m z} over the sorted bodies (4 doubles each)
 };
 struct TreeCat {  // sharded runs: side buffer of the device build
@@ -163,6 +164,13 @@ int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_u
                    void* workspace, size_t n_cap, int* out_info, TreeDevWork* work);
 int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
                      float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge);
+// the two halves of tree_emit_sorted, for the spatial-shard build (the nodes are emitted after an exchange, at an offset
+// in the global-index array, with each node's parent and depth)
+int tree_scan_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info,
+                     const int* edge);
+int tree_emit_nodes(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
+                    float4* nodes, int node_cap, int slice_cap, int* order, int* out_info, int want_hot, const int* edge,
+                    const int* node_offset, int* parent, unsigned char* depth);
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
                            int* n_anc, int* anc, int max_anc, const int* info = nullptr /* device: {n_nodes, flags, n}: overrides n, n_nodes */,
                            int* poison = nullptr /* made sticky when the build raised a flag */);

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void k_bh_walk_coop(const NodeDev* __restrict__
 // orthant order -- a fixed order, but not the pre-order of k_bh_walk: accelerations agree to rounding, not bit for bit.
 // The node-range split works on the records' pre-order indices: a subtree entirely outside [s0, s1) is not touched,
 // a node before s0 whose subtree reaches into the range is only tested (it belongs to an earlier segment).
-constexpr int kBlockStack = 160;   // entries; a walk holds <= 7 per level + 1, the device build stops at 21 levels
+constexpr int kBlockStack = 320;   // entries; a walk holds <= 7 per level + 1, the device build stops at 42 levels
 
 template <bool DIRECT, bool DBG = false>
 __global__ __launch_bounds__(64) void k_bh_walk_block(const NodeDev* __restrict__ bfs, int n_nodes,

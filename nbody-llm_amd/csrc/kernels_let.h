@@ -15,10 +15,15 @@ struct Migrant {                // a body on its way to the rank that owns its k
     int id, pad[3];
 };
 
-struct EndInfo {                // what every rank tells the others after its sort (48 bytes, all-gathered)
+constexpr int kBoxDigits = 2;   // a rank describes where its bodies are by one bounding box per child cell, this many levels
+constexpr int kBoxes = 1 << (3 * kBoxDigits);   // below the deepest cell that holds all of them (a key range is not a box: a
+                                // range that straddles the boundary of two big cells has a bounding box that spans both)
+
+struct EndInfo {                // what every rank tells the others after its sort (all-gathered)
     unsigned long long first_key, last_key;   // of its sorted bodies
     int n_bodies, pad;
-    float lo[3], hi[3];                       // bounding box of its bodies
+    float lo[3], hi[3];                       // bounding box of all its bodies (quick reject)
+    float box_lo[kBoxes][3], box_hi[kBoxes][3];   // of its bodies in each child cell; lo > hi: none there
 };
 
 struct Contrib {                // [r][d]: what a rank adds to the cell of depth d on rank r's LAST body's path (40 bytes)
@@ -33,25 +38,26 @@ struct RoundB {                 // what every rank tells the others after its lo
     Contrib c[kMaxRanks][kLevels];
 };
 
-struct LetRecord {              // an exported node: the record and where it goes in the global array (48 bytes)
-    float4 a, b;
-    int index, pad[3];
+struct LetRecord {              // an exported node (32 bytes): the record; b.z (NodeB::hot, which the plain walk does not read)
+    float4 a, b;                // carries its index in the global array
 };
 
 void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float center[3], float width, const unsigned long long* bounds,
-                     int G, int me, Migrant* send, int* send_count, int mig_cap, int* flags);
+                     int G, int me, Migrant* send, int* send_count, int mig_cap, int* flags, bool after_drift);
 void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, const int* recv_count, int G, int mig_cap, int* flags,
                    int* new_count, int* send_count);
-void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, int* box_ord, EndInfo* mine);
+void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
+                 EndInfo* mine);
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge);
 void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
                     RoundB* mine);
-void launch_finalize(hipStream_t s, const float4* local_nodes, int local_cap, const int* info, const RoundB* rb, const EndInfo* ends, int G,
-                     int me, float width, float4* global_nodes, int global_cap, int* offsets, int* top_index, int* out_flags);
-void launch_flags_and_pack(hipStream_t s, const Shard& sh, const TreeDevWork& w, int local_cap, const int* info, const int* edge,
-                           const float4* global_nodes, const int* offsets, const int* top_index, const EndInfo* ends, int G, int me,
-                           float theta2, int* parent, unsigned char* depth, unsigned int* upper_ok, unsigned int* flags, int* let_count,
-                           LetRecord* send, size_t send_stride, int* cursor, bool prune);
+void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags);
+void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
+                     const int* offsets, int* top_index);
+void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const int* edge, const float4* global_nodes, const int* offsets,
+                           const int* top_index, const EndInfo* ends, int G, int me, float theta2, const int* parent,
+                           const unsigned char* depth, unsigned int* upper_ok, int2* link, int* let_count, LetRecord* send,
+                           size_t send_stride, bool prune);
 void launch_scatter(hipStream_t s, const LetRecord* recv, int n, float4* global_nodes, int global_cap);
 
 }  // namespace let

@@ -15,8 +15,8 @@
 //     skip link the first node behind them: every rank works out what it adds to every earlier rank's spanning cells
 //     (k_let_contrib), one all-gather of those small tables, and everybody knows all spanning cells (k_let_finalize);
 //   * everything else is private to a rank's slice.  A partner needs a private node only if one of its bodies can get
-//     there, i.e. if it can OPEN every ancestor: k_let_flags tests the ancestors against the partners' bounding boxes
-//     (opening test of barnes_hut.rs:192 with the box's nearest point), k_let_pack writes {global index, record} lists,
+//     there, i.e. if it can OPEN every ancestor: k_let_open_masks / k_let_flag_pack test the ancestors against the boxes the partners' bodies lie in
+//     (opening test of barnes_hut.rs:192 with the box's nearest point) and write one list of records per partner,
 //     one variable-size send/recv round, k_let_scatter drops them at their global indices in the receiver's array.
 // The walk (k_bh_walk) then runs over that array as over a complete tree: every node a body visits is there.
 // Fast math, device build; node values come from f64 prefix sums over the LOCAL sorted order, so against the single-shard
@@ -63,14 +63,13 @@ __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i
 
 // Could some body inside the box fail the acceptance test w^2 < theta2 * r^2 on this node (i.e. open it)?  Conservative:
 // "no" only when the box's nearest point accepts it with a margin that covers the rounding of the walk's own r^2.
-__device__ __forceinline__ bool could_open(const float4 A, float w2, const float* lo, const float* hi, float theta2) {
+__device__ __forceinline__ bool box_could_open(const float4 A, float w2, const float* lo, const float* hi, float theta2) {
     const float dx = fmaxf(0.f, fmaxf(lo[0] - A.x, A.x - hi[0]));
     const float dy = fmaxf(0.f, fmaxf(lo[1] - A.y, A.y - hi[1]));
     const float dz = fmaxf(0.f, fmaxf(lo[2] - A.z, A.z - hi[2]));
     const float d2 = dx * dx + dy * dy + dz * dz;
     return !(w2 < theta2 * d2 * 0.9999f);
 }
-
 // ---- migration: a body whose key left this rank's range goes to the rank that owns it
 __global__ __launch_bounds__(256) void k_let_classify(const float4* __restrict__ pos, const float4* __restrict__ vel,
                                                       const float4* __restrict__ acc, const int* __restrict__ ids,
@@ -78,15 +77,16 @@ __global__ __launch_bounds__(256) void k_let_classify(const float4* __restrict__
                                                       const unsigned long long* __restrict__ bounds, int G, int me,
                                                       unsigned char* __restrict__ keep, int* __restrict__ escaped,
                                                       Migrant* __restrict__ send, int* __restrict__ send_count, int mig_cap,
-                                                      int* __restrict__ flags) {
+                                                      int* __restrict__ flags, int after_drift) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= *count) return;
+    if (after_drift && !keep[k]) return;   // left the box in this step's drift: the retain pass below drops it with the emigrants
     const float4 p = pos[k];
     const unsigned long long key = key_of(p, cx, cy, cz, width);
     int dest = 0;   // last r with bounds[r] <= key
     for (int r = 1; r < G; ++r) if (bounds[r] <= key) dest = r;
-    keep[k] = dest == me ? 1 : 0;      // (every flag is written: the ones drift_half left belong to the indices before its retain)
-    if (dest == me) return;            // an emigrant leaves this rank: a second retain pass (k_compact) closes the gap
+    keep[k] = dest == me ? 1 : 0;      // (outside a step every flag is written here: the old ones belong to an earlier retain)
+    if (dest == me) return;            // an emigrant leaves this rank: the retain pass (k_compact) closes the gap
     atomicAdd(escaped, 1);
     const int slot = atomicAdd(&send_count[dest], 1);
     if (slot >= mig_cap) { atomicOr(flags, kFlagMigOverflow); return; }
@@ -118,43 +118,55 @@ __global__ __launch_bounds__(256) void k_let_append(float4* __restrict__ pos, fl
     const Migrant m = recv[size_t(src) * mig_cap + within];
     pos[d] = m.pos; vel[d] = m.vel; acc[d] = m.acc; ids[d] = m.id;
 }
-__global__ void k_let_commit_count(int* __restrict__ count, const int* __restrict__ new_count, int* __restrict__ send_count, int G) {
+__global__ void k_let_commit_count(int* __restrict__ count, const int* __restrict__ new_count, int* __restrict__ send_count, int G,
+                                   int* __restrict__ migrated) {
     if (threadIdx.x == 0) *count = *new_count;
-    if (int(threadIdx.x) < G) send_count[threadIdx.x] = 0;   // ready for the next step's classification
+    if (int(threadIdx.x) < G) {
+        if (send_count[threadIdx.x] > 0) atomicAdd(migrated, send_count[threadIdx.x]);   // bookkeeping (NbodyLetStats.bodies_migrated)
+        send_count[threadIdx.x] = 0;   // ready for the next step's classification
+    }
 }
 
 // ---- what the other ranks need to know about this one before the second half of the build
-__global__ __launch_bounds__(256) void k_let_box(const float4* __restrict__ pos, const int* __restrict__ count, int* __restrict__ box_ord) {
-    __shared__ int red[6][256];
-    const int k = blockIdx.x * 256 + threadIdx.x;
+// box_ord[0..5] = the overall box, box_ord[6 + 6 b ..] = the box of child cell b, as order-preserving ints (min / max atomics)
+__global__ __launch_bounds__(256) void k_let_box(const float4* __restrict__ pos, const unsigned long long* __restrict__ keys,
+                                                 const int* __restrict__ ids, const int* __restrict__ count, int* __restrict__ box_ord) {
+    __shared__ int red[kBoxes + 1][6];
     const int n = *count;
-    int v[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, int(0x80000000), int(0x80000000), int(0x80000000)};
-    if (k < n) {
-        const float4 p = pos[k];
-        v[0] = v[3] = f2ord(p.x); v[1] = v[4] = f2ord(p.y); v[2] = v[5] = f2ord(p.z);
-    }
-    for (int c = 0; c < 6; ++c) red[c][threadIdx.x] = v[c];
+    for (int t = threadIdx.x; t < (kBoxes + 1) * 6; t += 256) red[t / 6][t % 6] = (t % 6) < 3 ? 0x7fffffff : int(0x80000000);
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (int(threadIdx.x) < off)
-            for (int c = 0; c < 6; ++c)
-                red[c][threadIdx.x] = c < 3 ? min(red[c][threadIdx.x], red[c][threadIdx.x + off]) : max(red[c][threadIdx.x], red[c][threadIdx.x + off]);
-        __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;   // sorted position
+    if (j < n) {
+        const int c = min(common_levels(keys[0], keys[n - 1]), kLevels - kBoxDigits);   // the deepest cell holding all my bodies
+        const int g = int((keys[j] >> (3 * (kLevels - kBoxDigits - c))) & (unsigned long long)(kBoxes - 1));
+        const float4 p = pos[ids[j]];
+        const int o[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&red[g][a], o[a]); atomicMax(&red[g][3 + a], o[a]);
+            atomicMin(&red[kBoxes][a], o[a]); atomicMax(&red[kBoxes][3 + a], o[a]);
+        }
     }
-    if (threadIdx.x < 3) atomicMin(&box_ord[threadIdx.x], red[threadIdx.x][0]);
-    else if (threadIdx.x < 6) atomicMax(&box_ord[threadIdx.x], red[threadIdx.x][0]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < (kBoxes + 1) * 6; t += 256) {
+        const int b = t / 6, a = t % 6, v = red[b][a];
+        int* dst = b == kBoxes ? &box_ord[a] : &box_ord[6 + 6 * b + a];
+        if (a < 3) { if (v != 0x7fffffff) atomicMin(dst, v); }
+        else if (v != int(0x80000000)) atomicMax(dst, v);
+    }
 }
 __global__ void k_let_ends(const unsigned long long* __restrict__ sorted_keys, const int* __restrict__ count, int* __restrict__ box_ord,
                            EndInfo* __restrict__ mine) {
-    if (threadIdx.x != 0) return;
     const int n = *count;
-    EndInfo e;
-    e.first_key = n > 0 ? sorted_keys[0] : 0ull;
-    e.last_key = n > 0 ? sorted_keys[n - 1] : 0ull;
-    e.n_bodies = n; e.pad = 0;
-    for (int c = 0; c < 3; ++c) { e.lo[c] = ord2f(box_ord[c]); e.hi[c] = ord2f(box_ord[3 + c]); }
-    *mine = e;
-    for (int c = 0; c < 3; ++c) { box_ord[c] = 0x7fffffff; box_ord[3 + c] = int(0x80000000); }   // for the next step
+    if (threadIdx.x == 0) {
+        mine->first_key = n > 0 ? sorted_keys[0] : 0ull;
+        mine->last_key = n > 0 ? sorted_keys[n - 1] : 0ull;
+        mine->n_bodies = n; mine->pad = 0;
+        for (int c = 0; c < 3; ++c) { mine->lo[c] = ord2f(box_ord[c]); mine->hi[c] = ord2f(box_ord[3 + c]); }
+    }
+    for (int b = threadIdx.x; b < kBoxes; b += blockDim.x)
+        for (int c = 0; c < 3; ++c) { mine->box_lo[b][c] = ord2f(box_ord[6 + 6 * b + c]); mine->box_hi[b][c] = ord2f(box_ord[6 + 6 * b + 3 + c]); }
+    __syncthreads();
+    for (int t = threadIdx.x; t < (kBoxes + 1) * 6; t += blockDim.x) box_ord[t] = (t % 6) < 3 ? 0x7fffffff : int(0x80000000);   // for the next step
 }
 
 // edge[0] / edge[1]: levels my first / last sorted body shares with the last / first body of the nearest rank before /
@@ -213,175 +225,188 @@ __global__ __launch_bounds__(64) void k_let_contrib(const unsigned long long* __
 }
 
 // ---- after the all-gather of the RoundB records
-// offsets[r] = first global index of rank r's slice, offsets[G] = total; top[r][d] = the finished spanning cells
+// offsets[r] = first global index of rank r's slice, offsets[G] = total
+__global__ void k_let_offsets(const RoundB* __restrict__ rb, int G, int global_cap, int* __restrict__ offsets, int* __restrict__ out_flags) {
+    if (threadIdx.x != 0) return;
+    int run = 0, fl = 0;
+    for (int q = 0; q < G; ++q) { offsets[q] = run; run += rb[q].n_nodes; fl |= rb[q].flags; }
+    offsets[G] = run;
+    if (run > global_cap) fl |= kFlagNodeCap;
+    if (fl) atomicOr(out_flags, fl);
+}
+// top[r][d] = the finished spanning cells (after the emit of my slice: it overwrites the ones that are mine)
 __global__ __launch_bounds__(64) void k_let_finalize(const RoundB* __restrict__ rb, const EndInfo* __restrict__ ends, int G, int me,
                                                      float width, float4* __restrict__ global_nodes, int global_cap,
-                                                     int* __restrict__ offsets, int* __restrict__ top_index /* [G][kLevels] global index or -1 */,
-                                                     int* __restrict__ out_flags) {
-    __shared__ int off_s[kMaxRanks + 1];
+                                                     const int* __restrict__ offsets, int* __restrict__ top_index /* [G][kLevels] global index or -1 */) {
     const int r = blockIdx.x, d = threadIdx.x;
-    if (d == 0) {
-        int run = 0, fl = 0;
-        for (int q = 0; q < G; ++q) { off_s[q] = run; run += rb[q].n_nodes; fl |= rb[q].flags; }
-        off_s[G] = run;
-        if (r == 0) {
-            for (int q = 0; q <= G; ++q) offsets[q] = off_s[q];
-            if (run > global_cap) fl |= kFlagNodeCap;
-            atomicOr(out_flags, fl);
-        }
-    }
-    __syncthreads();
     if (d >= kLevels) return;
+    const int total = offsets[G];
     const Contrib own = rb[r].c[r][d];
     int gi = -1;
-    if (own.base_after >= 0 && off_s[G] <= global_cap) {
+    if (own.base_after >= 0 && total <= global_cap) {
         double m = own.m, mx = own.mx, my = own.my, mz = own.mz;
-        int skip = off_s[G];
+        int skip = total;
         for (int q = r + 1; q < G; ++q) {     // the later ranks, in order, until one still has a body beyond the cell
             if (ends[q].n_bodies <= 0) continue;
             const Contrib c = rb[q].c[r][d];
             m += c.m; mx += c.mx; my += c.my; mz += c.mz;
-            if (c.cnt < ends[q].n_bodies) { skip = off_s[q] + c.base_after; break; }
+            if (c.cnt < ends[q].n_bodies) { skip = offsets[q] + c.base_after; break; }
         }
         float w = width;
         for (int q = 0; q < d; ++q) w = w * 0.5f;    // create_orthant halves the width exactly
-        gi = off_s[r] + own.base_after;
+        gi = offsets[r] + own.base_after;
         global_nodes[2 * gi] = make_float4(float(mx / m), float(my / m), float(mz / m), float(m));
         global_nodes[2 * gi + 1] = make_float4(w * w, __int_as_float(skip), __int_as_float(0), __int_as_float(-1));
     }
     top_index[r * kLevels + d] = gi;
 }
 
-// my slice -> its place in the global array (indices shifted); must run BEFORE k_let_finalize overwrites the spanning cells
-__global__ __launch_bounds__(256) void k_let_place_slice(const float4* __restrict__ local_nodes, const int* __restrict__ info,
-                                                         const RoundB* __restrict__ rb, int me, float4* __restrict__ global_nodes,
-                                                         int global_cap) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= info[0]) return;
-    int off = 0;
-    for (int q = 0; q < me; ++q) off += rb[q].n_nodes;
-    if (off + i >= global_cap) return;
-    const float4 a = local_nodes[2 * i];
-    float4 b = local_nodes[2 * i + 1];
-    b.y = __int_as_float(__float_as_int(b.y) + off);
-    global_nodes[2 * (off + i)] = a;
-    global_nodes[2 * (off + i) + 1] = b;
+// ---- which of my private nodes could a partner's bodies reach?  (parent[] / depth[] of the slice come from the emit)
+// upper_ok[d] = bit mask of the partners that can open EVERY spanning cell on my first body's path from the root down
+// to depth d (those cells belong to earlier ranks); upper_ok[-1] := all.  One thread per (partner, child-cell box): its
+// box sits in registers while the block goes down the <= 21 cells.
+__global__ __launch_bounds__(kMaxRanks * kBoxes) void k_let_upper(const float4* __restrict__ global_nodes, const int* __restrict__ top_index,
+                                                                  const EndInfo* __restrict__ ends, const int* __restrict__ edge, int G, int me,
+                                                                  float theta2, unsigned int* __restrict__ upper_ok) {
+    __shared__ unsigned int cell_ok[kLevels];   // partners that could open the spanning cell of depth d above my first body
+    __shared__ int cell_gi[kLevels];
+    const int r = threadIdx.x / kBoxes, b = threadIdx.x % kBoxes;
+    const int e0 = edge[0];
+    if (threadIdx.x < kLevels) {
+        const int d = threadIdx.x;
+        cell_ok[d] = 0u;
+        int gi = -1;
+        if (d <= e0) {   // the cell of depth d that contains my first body: one of the spanning cells of an earlier rank
+            const unsigned long long fk = ends[me].first_key;
+            for (int q = 0; q < me && gi < 0; ++q)
+                if (top_index[q * kLevels + d] >= 0 && ends[q].n_bodies > 0 && prefix_lo(ends[q].last_key, d) == prefix_lo(fk, d))
+                    gi = top_index[q * kLevels + d];
+        }
+        cell_gi[d] = gi;
+    }
+    __syncthreads();
+    const bool partner = r < G && r != me && ends[r].n_bodies > 0;
+    float lo[3] = {1.f, 1.f, 1.f}, hi[3] = {0.f, 0.f, 0.f};
+    if (partner) for (int c = 0; c < 3; ++c) { lo[c] = ends[r].box_lo[b][c]; hi[c] = ends[r].box_hi[b][c]; }
+    if (partner && lo[0] <= hi[0])
+        for (int d = 0; d <= e0 && d < kLevels; ++d) {
+            const int gi = cell_gi[d];
+            if (gi >= 0 && box_could_open(global_nodes[2 * gi], global_nodes[2 * gi + 1].x, lo, hi, theta2)) atomicOr(&cell_ok[d], 1u << r);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int mask = 0;
+        for (int q = 0; q < G; ++q) if (q != me && ends[q].n_bodies > 0) mask |= 1u << q;
+        for (int d = 0; d < kLevels; ++d) { if (cell_gi[d] >= 0) mask &= cell_ok[d]; upper_ok[d] = mask; }
+    }
 }
 
-// ---- which of my private nodes could a partner's bodies reach?
-// parent[i]: index in my slice of node i's parent; -1: none (the root); <= -2: the parent is the spanning cell of depth
-// (-p - 2) on my FIRST body's path, which an earlier rank owns
-__global__ __launch_bounds__(256) void k_let_parents(const unsigned long long* __restrict__ keys, const signed char* __restrict__ delta,
-                                                     const int* __restrict__ base, const int* __restrict__ count,
-                                                     const int* __restrict__ info, const int* __restrict__ edge,
-                                                     int* __restrict__ parent, unsigned char* __restrict__ depth_out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int n = *count;
-    if (n <= 0 || idx >= info[0]) return;
-    int lo = 0, hi = n - 1;             // the body whose nodes include idx: last k with base[k] <= idx
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (base[mid] <= idx) lo = mid; else hi = mid - 1; }
-    const int k = lo;
-    const int d_next = delta[k];
-    const int d_prev = k > 0 ? delta[k - 1] : edge[0];
-    const int opened = max(0, d_next - d_prev);
-    const int t = idx - base[k];
-    const int d = t < opened ? d_prev + 1 + t : max(d_prev, d_next) + 1;
-    depth_out[idx] = (unsigned char)d;
-    int par;
-    if (d == 0) par = -1;
-    else if (t >= 1) par = idx - 1;     // the cell this body opened one level up
-    else {                              // opened by an earlier body: the first one that shares d - 1 levels with k
-        const int pd = d - 1;
-        const unsigned long long lo_key = prefix_lo(keys[k], pd);
-        int a = 0, b = k;
-        while (a < b) { const int mid = (a + b) >> 1; if (keys[mid] >= lo_key) b = mid; else a = mid + 1; }
-        const int kf = a;
-        if (kf == 0 && pd <= edge[0]) par = -(pd + 2);   // ... sits on an earlier rank
-        else {
-            const int dp = kf > 0 ? delta[kf - 1] : edge[0];
-            par = base[kf] + (pd - (dp + 1));
+// link[i] = {parent of my node i, the partners that could open it (0 for a leaf)}: one pass over the slice, so that the
+// ancestor walk below only ANDs words (testing every ancestor of every node against the boxes was 2 ms at 776 000 nodes).
+// The partners' non-empty boxes are staged in LDS once per block.
+__global__ __launch_bounds__(256) void k_let_open_masks(const float4* __restrict__ global_nodes, const int* __restrict__ offsets,
+                                                        const int* __restrict__ info, const EndInfo* __restrict__ ends, int G, int me,
+                                                        float theta2, const int* __restrict__ parent, int2* __restrict__ link) {
+    __shared__ float outer[kMaxRanks][6];
+    __shared__ float sub[kMaxRanks][kBoxes][6];
+    __shared__ int n_sub[kMaxRanks];
+    if (int(blockIdx.x) * 256 >= info[0]) return;
+    if (threadIdx.x < kMaxRanks) n_sub[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < G * kBoxes; t += 256) {
+        const int r = t / kBoxes, b = t % kBoxes;
+        if (r == me || ends[r].n_bodies <= 0) continue;
+        if (b == 0) for (int c = 0; c < 3; ++c) { outer[r][c] = ends[r].lo[c]; outer[r][3 + c] = ends[r].hi[c]; }
+        if (ends[r].box_lo[b][0] <= ends[r].box_hi[b][0]) {
+            const int slot = atomicAdd(&n_sub[r], 1);
+            for (int c = 0; c < 3; ++c) { sub[r][slot][c] = ends[r].box_lo[b][c]; sub[r][slot][3 + c] = ends[r].box_hi[b][c]; }
         }
     }
-    parent[idx] = par;
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= info[0]) return;
+    const int gi = offsets[me] + idx;
+    const float4 B = global_nodes[2 * gi + 1];
+    unsigned int mask = 0;
+    if (__float_as_int(B.w) < 0) {      // a cell
+        const float4 A = global_nodes[2 * gi];
+        for (int r = 0; r < G; ++r) {
+            if (r == me || n_sub[r] == 0) continue;
+            if (!box_could_open(A, B.x, &outer[r][0], &outer[r][3], theta2)) continue;
+            bool open = theta2 == 0.f;  // pruning off
+            for (int b = 0; b < n_sub[r] && !open; ++b) open = box_could_open(A, B.x, &sub[r][b][0], &sub[r][b][3], theta2);
+            if (open) mask |= 1u << r;
+        }
+    }
+    link[idx] = make_int2(parent[idx], int(mask));
 }
 
-// upper_ok[d] = bit mask of the partners that can open EVERY spanning cell on my first body's path from the root down
-// to depth d (those cells belong to earlier ranks); upper_ok[-1] := all
-__global__ void k_let_upper(const float4* __restrict__ global_nodes, const int* __restrict__ top_index, const EndInfo* __restrict__ ends,
-                            const int* __restrict__ edge, int G, int me, float theta2, unsigned int* __restrict__ upper_ok) {
-    if (threadIdx.x != 0) return;
+// A node goes to partner r if r could open every one of its ancestors.  The lists are filled in whatever order the blocks
+// arrive (the receiver scatters by index); a block takes its slots of a list with ONE atomic (one per node and partner
+// was a million atomics on seven addresses).
+constexpr int kPackThreads = 1024;
+__global__ __launch_bounds__(kPackThreads) void k_let_flag_pack(const float4* __restrict__ global_nodes, const int* __restrict__ offsets,
+                                                                const int* __restrict__ info, const unsigned char* __restrict__ depth,
+                                                                const int* __restrict__ top_index, const EndInfo* __restrict__ ends,
+                                                                const unsigned int* __restrict__ upper_ok, const int2* __restrict__ link,
+                                                                int G, int me, LetRecord* __restrict__ send, size_t send_stride,
+                                                                int* __restrict__ let_count) {
+    __shared__ int wave_n[kPackThreads / 64][kMaxRanks];   // records of each wave for each partner, then their first slot
+    if (int(blockIdx.x) * kPackThreads >= info[0]) return;
+    const int idx = blockIdx.x * kPackThreads + threadIdx.x;
+    const int off = offsets[me];
     unsigned int mask = 0;
-    for (int r = 0; r < G; ++r) if (r != me && ends[r].n_bodies > 0) mask |= 1u << r;
-    const unsigned long long fk = ends[me].first_key;
-    for (int d = 0; d < kLevels; ++d) {
-        if (d <= edge[0]) {
-            // the cell of depth d that contains my first body: one of the spanning cells of an earlier rank
-            int gi = -1;
-            for (int r = 0; r < me && gi < 0; ++r)
-                if (top_index[r * kLevels + d] >= 0 && ends[r].n_bodies > 0 && prefix_lo(ends[r].last_key, d) == prefix_lo(fk, d))
-                    gi = top_index[r * kLevels + d];
-            if (gi >= 0) {
-                const float4 A = global_nodes[2 * gi], B = global_nodes[2 * gi + 1];
-                for (int r = 0; r < G; ++r)
-                    if ((mask >> r) & 1u) if (!could_open(A, B.x, ends[r].lo, ends[r].hi, theta2)) mask &= ~(1u << r);
+    if (idx < info[0]) {
+        const int d0 = depth[idx];
+        if (!(d0 < kLevels && top_index[me * kLevels + d0] == off + idx)) {   // (my own spanning cells are known to everybody already)
+            for (int r = 0; r < G; ++r) if (r != me && ends[r].n_bodies > 0) mask |= 1u << r;
+            int p = link[idx].x;
+            while (mask != 0u && p != -1) {
+                if (p <= -2) { mask &= upper_ok[-p - 2]; break; }
+                const int2 l = link[p];
+                mask &= (unsigned int)l.y;
+                p = l.x;
             }
         }
-        upper_ok[d] = mask;
     }
-}
-
-__global__ __launch_bounds__(256) void k_let_flags(const float4* __restrict__ global_nodes, const int* __restrict__ offsets,
-                                                   const int* __restrict__ info, const int* __restrict__ parent,
-                                                   const unsigned char* __restrict__ depth, const int* __restrict__ top_index,
-                                                   const EndInfo* __restrict__ ends, const unsigned int* __restrict__ upper_ok,
-                                                   int G, int me, float theta2, unsigned int* __restrict__ flags,
-                                                   int* __restrict__ let_count) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= info[0]) return;
-    const int off = offsets[me];
-    // my own spanning cells are known to everybody already
-    const int d0 = depth[idx];
-    unsigned int mask = 0;
-    if (!(d0 < kLevels && top_index[me * kLevels + d0] == off + idx)) {
-        for (int r = 0; r < G; ++r) if (r != me && ends[r].n_bodies > 0) mask |= 1u << r;
-        int p = parent[idx];
-        while (mask != 0u && p != -1) {
-            if (p <= -2) { mask &= upper_ok[-p - 2]; break; }
-            const float4 A = global_nodes[2 * (off + p)], B = global_nodes[2 * (off + p) + 1];
-            for (int r = 0; r < G; ++r)
-                if ((mask >> r) & 1u) if (!could_open(A, B.x, ends[r].lo, ends[r].hi, theta2)) mask &= ~(1u << r);
-            p = parent[p];
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = 0; r < G; ++r) {
+        const unsigned long long vote = __ballot((mask >> r) & 1u);
+        if (lane == 0) wave_n[wave][r] = __popcll(vote);
     }
-    flags[idx] = mask;
-    for (int r = 0; r < G; ++r) if ((mask >> r) & 1u) atomicAdd(&let_count[r], 1);
-}
-
-__global__ __launch_bounds__(256) void k_let_pack(const float4* __restrict__ global_nodes, const int* __restrict__ offsets,
-                                                  const int* __restrict__ info, const unsigned int* __restrict__ flags, int G, int me,
-                                                  LetRecord* __restrict__ send, size_t send_stride, int* __restrict__ cursor) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= info[0]) return;
-    const unsigned int mask = flags[idx];
+    __syncthreads();
+    if (int(threadIdx.x) < G) {          // thread r: the block's records for partner r -> one atomic, then every wave's first slot
+        const int r = threadIdx.x;
+        int total = 0;
+        for (int w = 0; w < kPackThreads / 64; ++w) total += wave_n[w][r];
+        int first = total > 0 ? atomicAdd(&let_count[r], total) : 0;
+        for (int w = 0; w < kPackThreads / 64; ++w) { const int c = wave_n[w][r]; wave_n[w][r] = first; first += c; }
+    }
+    __syncthreads();
     if (mask == 0u) return;
-    const int gi = offsets[me] + idx;
     LetRecord rec;
-    rec.a = global_nodes[2 * gi]; rec.b = global_nodes[2 * gi + 1]; rec.index = gi; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
-    for (int r = 0; r < G; ++r)
-        if ((mask >> r) & 1u) {
-            const int slot = atomicAdd(&cursor[r], 1);   // (the order inside a list does not matter: the receiver scatters by index)
-            if (size_t(slot) < send_stride) send[size_t(r) * send_stride + slot] = rec;
+    rec.a = global_nodes[2 * (off + idx)]; rec.b = global_nodes[2 * (off + idx) + 1];
+    rec.b.z = __int_as_float(off + idx);   // the slot of NodeB::hot carries the global index (the plain walk does not read it)
+    for (int r = 0; r < G; ++r) {
+        const bool mine = (mask >> r) & 1u;
+        const unsigned long long vote = __ballot(mine);
+        if (mine) {
+            const size_t slot = size_t(wave_n[wave][r]) + size_t(__popcll(vote & ((1ull << lane) - 1ull)));
+            if (slot < send_stride) send[size_t(r) * send_stride + slot] = rec;
         }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_let_scatter(const LetRecord* __restrict__ recv, int n, float4* __restrict__ global_nodes,
                                                      int global_cap) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const LetRecord rec = recv[j];
-    if (rec.index < 0 || rec.index >= global_cap) return;
-    global_nodes[2 * rec.index] = rec.a;
-    global_nodes[2 * rec.index + 1] = rec.b;
+    LetRecord rec = recv[j];
+    const int index = __float_as_int(rec.b.z);
+    if (index < 0 || index >= global_cap) return;
+    rec.b.z = __int_as_float(0);
+    global_nodes[2 * index] = rec.a;
+    global_nodes[2 * index + 1] = rec.b;
 }
 
 inline dim3 grid_for(int n, int bs) { return dim3((std::max(n, 1) + bs - 1) / bs); }
@@ -389,19 +414,21 @@ inline dim3 grid_for(int n, int bs) { return dim3((std::max(n, 1) + bs - 1) / bs
 }  // namespace
 
 void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float center[3], float width, const unsigned long long* bounds,
-                     int G, int me, Migrant* send, int* send_count, int mig_cap, int* flags) {
+                     int G, int me, Migrant* send, int* send_count, int mig_cap, int* flags, bool after_drift) {
     if (n_upper <= 0) return;
     hipLaunchKernelGGL(k_let_classify, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(),
-                       center[0], center[1], center[2], width, bounds, G, me, sh.keep, sh.escaped, send, send_count, mig_cap, flags);
+                       center[0], center[1], center[2], width, bounds, G, me, sh.keep, sh.escaped, send, send_count, mig_cap, flags, after_drift ? 1 : 0);
 }
 void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, const int* recv_count, int G, int mig_cap, int* flags,
                    int* new_count, int* send_count) {
     hipLaunchKernelGGL(k_let_append, grid_for(G * mig_cap, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(),
                        sh.seg_cap, recv, recv_count, G, mig_cap, flags, new_count);
-    hipLaunchKernelGGL(k_let_commit_count, dim3(1), dim3(64), 0, s, sh.own_count(), new_count, send_count, G);
+    hipLaunchKernelGGL(k_let_commit_count, dim3(1), dim3(64), 0, s, sh.own_count(), new_count, send_count, G, flags + 2);
 }
-void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, int* box_ord, EndInfo* mine) {
-    if (n_upper > 0) hipLaunchKernelGGL(k_let_box, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sh.own_count(), box_ord);
+void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
+                 EndInfo* mine) {
+    if (n_upper > 0)
+        hipLaunchKernelGGL(k_let_box, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sorted_keys, sorted_ids, sh.own_count(), box_ord);
     hipLaunchKernelGGL(k_let_ends, dim3(1), dim3(64), 0, s, sorted_keys, sh.own_count(), box_ord, mine);
 }
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge) {
@@ -412,23 +439,24 @@ void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const 
     hipLaunchKernelGGL(k_let_contrib, dim3(G), dim3(64), 0, s, w.keys, w.delta, w.base, static_cast<const Sum4*>(w.incl), sh.own_count(), info,
                        ends, edge, G, me, mine);
 }
-void launch_finalize(hipStream_t s, const float4* local_nodes, int local_cap, const int* info, const RoundB* rb, const EndInfo* ends, int G,
-                     int me, float width, float4* global_nodes, int global_cap, int* offsets, int* top_index, int* out_flags) {
-    hipLaunchKernelGGL(k_let_place_slice, grid_for(local_cap, 256), dim3(256), 0, s, local_nodes, info, rb, me, global_nodes, global_cap);
-    hipLaunchKernelGGL(k_let_finalize, dim3(G), dim3(64), 0, s, rb, ends, G, me, width, global_nodes, global_cap, offsets, top_index, out_flags);
+void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags) {
+    hipLaunchKernelGGL(k_let_offsets, dim3(1), dim3(64), 0, s, rb, G, global_cap, offsets, out_flags);
 }
-void launch_flags_and_pack(hipStream_t s, const Shard& sh, const TreeDevWork& w, int local_cap, const int* info, const int* edge,
-                           const float4* global_nodes, const int* offsets, const int* top_index, const EndInfo* ends, int G, int me,
-                           float theta2, int* parent, unsigned char* depth, unsigned int* upper_ok, unsigned int* flags, int* let_count,
-                           LetRecord* send, size_t send_stride, int* cursor, bool prune) {
-    hipLaunchKernelGGL(k_let_parents, grid_for(local_cap, 256), dim3(256), 0, s, w.keys, w.delta, w.base, sh.own_count(), info, edge, parent, depth);
+void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
+                     const int* offsets, int* top_index) {
+    hipLaunchKernelGGL(k_let_finalize, dim3(G), dim3(64), 0, s, rb, ends, G, me, width, global_nodes, global_cap, offsets, top_index);
+}
+void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const int* edge, const float4* global_nodes, const int* offsets,
+                           const int* top_index, const EndInfo* ends, int G, int me, float theta2, const int* parent,
+                           const unsigned char* depth, unsigned int* upper_ok, int2* link, int* let_count, LetRecord* send,
+                           size_t send_stride, bool prune) {
     // prune = false: theta2 = 0 makes every node "openable": every private node goes to every partner (the test switch
     // that shows the pruning changes nothing but the volume)
     const float t2 = prune ? theta2 : 0.f;
-    hipLaunchKernelGGL(k_let_upper, dim3(1), dim3(64), 0, s, global_nodes, top_index, ends, edge, G, me, t2, upper_ok);
-    hipLaunchKernelGGL(k_let_flags, grid_for(local_cap, 256), dim3(256), 0, s, global_nodes, offsets, info, parent, depth, top_index, ends,
-                       upper_ok, G, me, t2, flags, let_count);
-    hipLaunchKernelGGL(k_let_pack, grid_for(local_cap, 256), dim3(256), 0, s, global_nodes, offsets, info, flags, G, me, send, send_stride, cursor);
+    hipLaunchKernelGGL(k_let_upper, dim3(1), dim3(kMaxRanks * kBoxes), 0, s, global_nodes, top_index, ends, edge, G, me, t2, upper_ok);
+    hipLaunchKernelGGL(k_let_open_masks, grid_for(local_cap, 256), dim3(256), 0, s, global_nodes, offsets, info, ends, G, me, t2, parent, link);
+    hipLaunchKernelGGL(k_let_flag_pack, grid_for(local_cap, kPackThreads), dim3(kPackThreads), 0, s, global_nodes, offsets, info, depth, top_index,
+                       ends, upper_ok, link, G, me, send, send_stride, let_count);
 }
 void launch_scatter(hipStream_t s, const LetRecord* recv, int n, float4* global_nodes, int global_cap) {
     if (n <= 0) return;

@@ -18,13 +18,21 @@
 //   5. emit: one thread per body writes its opened cells and its leaf.  A cell's last body is found
 //                by binary search on the sorted keys (all keys sharing its prefix), its skip link is
 //                the pre-order index after that body's leaf.
-// Bodies whose 63-bit keys collide need more than 21 levels: the build reports it and the caller
-// falls back to the host build (which goes to depth 192).
+// Bodies whose 63-bit keys collide (at N = 2^22 in a Plummer sphere there is about one such pair at any time: cells of
+// level 21 are 3e-5 wide) get a SECOND key, levels 21..41, computed and ordered inside their group of equal first keys
+// by the group's first thread (k_tree_ties); delta then runs to 42 and the cells below level 21 are found by walking the
+// group instead of a binary search.  Bodies that agree on all 42 levels (coincident for f32 purposes: the cell width is
+// far below an ulp of the coordinates by then) make the build report "too deep"; the one-GPU caller falls back to the
+// host build (which goes to depth 192 before it gives up), the spatial-shard caller returns NBODY_ERR_TREE_DEPTH.
 #include "kernels.h"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+
+// test hook: the largest group of equal 63-bit keys the device build orders itself (1: any collision is "too deep", which
+// exercises the callers' fallback paths the way every collision did before the second keys existed)
+extern "C" int nbody_tree_max_tie = 64;
 
 namespace nbody {
 
@@ -36,6 +44,22 @@ struct Sum4 { double m, x, y, z; };
 struct Sum4Plus {
     __host__ __device__ Sum4 operator()(const Sum4& a, const Sum4& b) const { return Sum4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
 };
+
+// the orthant codes of kLevels levels starting at level `first` (0: the sort key; kLevels: the tie-break key)
+__device__ __forceinline__ unsigned long long orthant_key(const float4 p, float cx, float cy, float cz, float width, int first) {
+    float hw = width * 0.5f;  // Bounds::new
+    unsigned long long key = 0;
+#pragma unroll 1
+    for (int l = 0; l < first + kLevels; ++l) {
+        const bool bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // get_orthant
+        key = (key << 3) | (unsigned long long)((bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0));   // (the levels before `first` fall off the top)
+        hw = hw * 0.5f;                                            // create_orthant
+        cx = bx ? cx + hw : cx - hw;
+        cy = by ? cy + hw : cy - hw;
+        cz = bz ? cz + hw : cz - hw;
+    }
+    return key & 0x7fffffffffffffffull;
+}
 
 __global__ __launch_bounds__(256) void k_tree_keys(const float4* __restrict__ pos, const int* __restrict__ count,
                                                    int n_upper, float cx0, float cy0, float cz0, float width,
@@ -49,20 +73,7 @@ __global__ __launch_bounds__(256) void k_tree_keys(const float4* __restrict__ po
         ids[k] = k;
         return;
     }
-    const float4 p = pos[k];
-    float cx = cx0, cy = cy0, cz = cz0;
-    float hw = width * 0.5f;  // Bounds::new
-    unsigned long long key = 0;
-#pragma unroll 1
-    for (int l = 0; l < kLevels; ++l) {
-        const bool bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // get_orthant
-        key = (key << 3) | (unsigned long long)((bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0));
-        hw = hw * 0.5f;                                            // create_orthant
-        cx = bx ? cx + hw : cx - hw;
-        cy = by ? cy + hw : cy - hw;
-        cz = bz ? cz + hw : cz - hw;
-    }
-    keys[k] = key;
+    keys[k] = orthant_key(pos[k], cx0, cy0, cz0, width, 0);
     ids[k] = k;
 }
 
@@ -71,21 +82,56 @@ __device__ __forceinline__ int common_levels(unsigned long long a, unsigned long
     if (x == 0) return kLevels;               // identical on all 21 levels
     return (__clzll((long long)x) - 1) / 3;   // bit 63 is unused
 }
+// levels two sorted neighbours share, 0 .. 2 kLevels (keys2 is only defined inside groups of equal first keys)
+__device__ __forceinline__ int common_levels2(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
+                                              int a, int b) {
+    const int c = common_levels(keys[a], keys[b]);
+    return c < kLevels ? c : kLevels + common_levels(keys2[a], keys2[b]);
+}
+
+// After the sort: the first body of every group of equal keys gives the group its second keys (levels 21..41) and puts
+// it in their order (insertion sort, stable: the radix sort left the ids ascending).  Groups are pairs in practice; one
+// of more than nbody_tree_max_tie bodies (64) is reported as too deep rather than sorted by a single thread.
+__global__ __launch_bounds__(256) void k_tree_ties(const float4* __restrict__ pos, const int* __restrict__ count, float cx0, float cy0,
+                                                   float cz0, float width, const unsigned long long* __restrict__ keys,
+                                                   unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
+                                                   int kMaxTie) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int n = *count;
+    if (j + 1 >= n) return;
+    const unsigned long long key = keys[j];
+    if (keys[j + 1] != key || (j > 0 && keys[j - 1] == key)) return;
+    int e = j + 2;
+    while (e < n && e - j <= kMaxTie && keys[e] == key) ++e;
+    if (e - j > kMaxTie) { atomicOr(flags, 1); return; }
+    for (int q = j; q < e; ++q) keys2[q] = orthant_key(pos[ids[q]], cx0, cy0, cz0, width, kLevels);
+    for (int q = j + 1; q < e; ++q) {
+        const unsigned long long k2 = keys2[q];
+        const int id = ids[q];
+        int r = q - 1;
+        while (r >= j && keys2[r] > k2) { keys2[r + 1] = keys2[r]; ids[r + 1] = ids[r]; --r; }
+        keys2[r + 1] = k2; ids[r + 1] = id;
+    }
+}
 
 // One thread per NODE (not per body: the first body of a big cell opens every level above it, and 15
 // cells x a 17-step binary search in one thread was the kernel's whole duration, 30 us).  Node idx
 // belongs to the body k with base[k] <= idx < base[k+1] (binary search); its t-th node is the cell of
 // depth delta[k-1]+1+t that the body opens, or -- the last one -- the body's leaf.
-__global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
                                                    const int* __restrict__ ids, const float4* __restrict__ pos,
                                                    const int* __restrict__ count, const signed char* __restrict__ delta,
                                                    const int* __restrict__ base, const Sum4* __restrict__ incl,
                                                    float width, float4* __restrict__ nodes, int node_cap,
                                                    int* __restrict__ order, int* __restrict__ out_info, int want_hot,
-                                                   const int* __restrict__ edge) {
+                                                   const int* __restrict__ edge, const int* __restrict__ node_offset,
+                                                   int* __restrict__ parent_out, unsigned char* __restrict__ depth_out) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
+    // spatial shards: the slice goes straight to its place in the global-index array (indices and links shifted)
+    const int off = node_offset ? *node_offset : 0;
     if (n == 0) {  // the reference's empty root (barnes_hut.rs:145)
+        if (node_offset) { if (idx == 0) { out_info[0] = 0; out_info[2] = 0; } return; }   // (a rank without bodies adds nothing to the world's tree)
         if (idx == 0) {
             if (node_cap >= 1) {
                 nodes[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -93,18 +139,12 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
             }
             out_info[0] = 1;
             out_info[2] = 0;
+            if (parent_out) { parent_out[0] = -1; depth_out[0] = 0; }
         }
         return;
     }
-    // nodes in all: the last sorted body's first node + what it emits -- its leaf, and in a rank's slice of a distributed
-    // build (edge != null) the cells it opens with the next rank's first body (a whole tree's last body opens none)
-    int total = base[n - 1] + 1;
-    if (edge) {
-        const int dp_last = n > 1 ? delta[n - 2] : edge[0];
-        total += max(0, int(delta[n - 1]) - dp_last);
-    }
-    if (idx == 0) { out_info[0] = total; out_info[2] = n; }  // (the live body count rides along: one read-back)
-    if (total > node_cap) { if (idx == 0) atomicOr(out_info + 1, 2); return; }
+    const int total = out_info[0];      // k_tree_scan: the last sorted body's first node + what it emits
+    if (off + total > node_cap) { if (idx == 0) atomicOr(out_info + 1, 2); return; }
     if (idx >= total) return;
     int lo = 0, hi = n - 1;             // the body whose nodes include idx: last k with base[k] <= idx
     while (lo < hi) {
@@ -119,8 +159,41 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
     const unsigned long long key = keys[k];
     // NodeB::hot (octree_host.h): bodies in the grandparent cell = sorted bodies sharing the first depth-2 levels
     const int my_depth = (t < opened) ? d_prev + 1 + t : max(d_prev, d_next) + 1;
+    if (parent_out) {
+        // index in the slice of the node's parent; -1: none (the root); <= -2: the cell of depth (-p - 2) on the slice's
+        // FIRST body's path that an earlier rank owns (spatial shards)
+        int par;
+        if (my_depth == 0) par = -1;
+        else if (t >= 1) par = idx - 1; // the cell this body opened one level up
+        else {                          // opened by an earlier body: the first one that shares my_depth - 1 levels with k
+            const int pd = my_depth - 1;
+            int a = 0, b = k;
+            if (pd > kLevels) {
+                a = k;
+                while (a > 0 && keys[a - 1] == key && common_levels(keys2[a - 1], keys2[k]) >= pd - kLevels) --a;
+            } else {
+                const int sh = 3 * (kLevels - pd);
+                const unsigned long long lo_key = sh >= 63 ? 0ull : (key >> sh) << sh;
+                while (a < b) { const int mid = (a + b) >> 1; if (keys[mid] >= lo_key) b = mid; else a = mid + 1; }
+            }
+            const int kf = a;
+            if (kf == 0 && edge && pd <= edge[0]) par = -(pd + 2);
+            else {
+                const int dp = kf > 0 ? delta[kf - 1] : (edge ? edge[0] : -1);
+                par = base[kf] + (pd - (dp + 1));
+            }
+        }
+        parent_out[idx] = par;
+        depth_out[idx] = (unsigned char)my_depth;
+    }
     int hot = n;
-    if (want_hot && my_depth >= 2) {   // (two more binary searches per node, 5 us at N = 65 536: only for the walk that uses it)
+    if (want_hot && my_depth - 2 > kLevels) {   // below level 21: the grandparent's bodies are neighbours inside the group of equal keys
+        const int lv = my_depth - 2 - kLevels;
+        int a = k, b = k;
+        while (a > 0 && keys[a - 1] == key && common_levels(keys2[a - 1], keys2[k]) >= lv) --a;
+        while (b + 1 < n && keys[b + 1] == key && common_levels(keys2[b + 1], keys2[k]) >= lv) ++b;
+        hot = b - a + 1;
+    } else if (want_hot && my_depth >= 2) {   // (two more binary searches per node, 5 us at N = 65 536: only for the walk that uses it)
         const int sh = 3 * (kLevels - (my_depth - 2));
         const unsigned long long lo_key = (key >> sh) << sh, hi_gp = lo_key | ((1ull << sh) - 1ull);
         int a = 0, b = k;               // first sorted body with key >= lo_key
@@ -132,12 +205,16 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
     }
     if (t < opened) {                   // a cell this body opens, shallowest first
         const int d = d_prev + 1 + t;   // depth of the cell: its bodies share d levels
-        const int shift = 3 * (kLevels - d);
-        const unsigned long long hi_key = key | ((shift >= 64) ? ~0ull : ((1ull << shift) - 1ull));
-        int a = k, b = n - 1;           // last sorted body with key <= hi_key
-        while (a < b) {
-            const int mid = (a + b + 1) >> 1;
-            if (keys[mid] <= hi_key) a = mid; else b = mid - 1;
+        int a = k, b = n - 1;
+        if (d > kLevels) {              // a cell below level 21: its bodies follow k inside the group of equal keys
+            while (a + 1 < n && keys[a + 1] == key && common_levels(keys2[k], keys2[a + 1]) >= d - kLevels) ++a;
+        } else {
+            const int shift = 3 * (kLevels - d);
+            const unsigned long long hi_key = key | ((shift >= 64) ? ~0ull : ((1ull << shift) - 1ull));
+            while (a < b) {             // last sorted body with key <= hi_key
+                const int mid = (a + b + 1) >> 1;
+                if (keys[mid] <= hi_key) a = mid; else b = mid - 1;
+            }
         }
         const int j = a;
         const Sum4 before = (k > 0) ? incl[k - 1] : Sum4{0.0, 0.0, 0.0, 0.0};
@@ -145,17 +222,17 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
         const double m = upto.m - before.m;
         float w = width;
         for (int q = 0; q < d; ++q) w = w * 0.5f;       // create_orthant halves the width exactly
-        const int skip = (j + 1 < n) ? base[j + 1] : total;
-        nodes[2 * idx] = make_float4(float((upto.x - before.x) / m), float((upto.y - before.y) / m),
-                                     float((upto.z - before.z) / m), float(m));
-        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(skip), __int_as_float(hot), __int_as_float(-1));
+        const int skip = off + ((j + 1 < n) ? base[j + 1] : total);
+        nodes[2 * size_t(off + idx)] = make_float4(float((upto.x - before.x) / m), float((upto.y - before.y) / m),
+                                                   float((upto.z - before.z) / m), float(m));
+        nodes[2 * size_t(off + idx) + 1] = make_float4(w * w, __int_as_float(skip), __int_as_float(hot), __int_as_float(-1));
     } else {                            // the body's leaf
         const int ld = max(d_prev, d_next) + 1;
         float w = width;
         for (int q = 0; q < ld; ++q) w = w * 0.5f;
         const int id = ids[k];
-        nodes[2 * idx] = pos[id];
-        nodes[2 * idx + 1] = make_float4(w * w, __int_as_float(idx + 1), __int_as_float(hot), __int_as_float(id));
+        nodes[2 * size_t(off + idx)] = pos[id];
+        nodes[2 * size_t(off + idx) + 1] = make_float4(w * w, __int_as_float(off + idx + 1), __int_as_float(hot), __int_as_float(id));
         order[k] = id;
     }
 }
@@ -163,7 +240,8 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
 // ancestors of the node-range split points (the walk's WalkSplit lists), root first.  Node t lies in
 // the run emitted by body k (base[k] <= t); its ancestors are the cells of depths 0 .. depth(t)-1 on
 // that body's path, each opened by the first sorted body that shares the prefix.
-__global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, const signed char* __restrict__ delta,
+__global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
+                                 const signed char* __restrict__ delta,
                                  const int* __restrict__ base, int n, int n_nodes, int n_split,
                                  int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc,
                                  const int* __restrict__ info, int* __restrict__ poison) {
@@ -197,12 +275,17 @@ __global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, co
     if (a == 0) n_anc[s] = min(depth, max_anc);
     if (a >= depth || a >= max_anc) return;
     const unsigned long long key = keys[k];
-    const int shift = 3 * (kLevels - a);
-    const unsigned long long lo_key = (shift >= 64) ? 0ull : (key >> shift) << shift;
-    int l2 = 0, h2 = k;        // first sorted body with key >= lo_key: it opened the depth-a cell
-    while (l2 < h2) {
-        const int mid = (l2 + h2) >> 1;
-        if (keys[mid] >= lo_key) h2 = mid; else l2 = mid + 1;
+    int l2 = 0, h2 = k;        // first sorted body inside the depth-a cell: it opened it
+    if (a > kLevels) {         // below level 21: inside the group of equal keys
+        l2 = k;
+        while (l2 > 0 && keys[l2 - 1] == key && common_levels(keys2[l2 - 1], keys2[k]) >= a - kLevels) --l2;
+    } else {
+        const int shift = 3 * (kLevels - a);
+        const unsigned long long lo_key = (shift >= 64) ? 0ull : (key >> shift) << shift;
+        while (l2 < h2) {
+            const int mid = (l2 + h2) >> 1;
+            if (keys[mid] >= lo_key) h2 = mid; else l2 = mid + 1;
+        }
     }
     const int kf = l2;
     const int dp = (kf > 0) ? delta[kf - 1] : -1;
@@ -245,6 +328,7 @@ __device__ __forceinline__ ScanItem block_inclusive_scan(ScanItem v, ScanItem* l
 // per sorted body k: delta[k] (common levels with its right neighbour), emit_count[k] (cells it opens + its leaf), the
 // Sum4 term; per tile of kScanTile bodies: the totals of both
 __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsigned long long* __restrict__ keys,
+                                                                     const unsigned long long* __restrict__ keys2,
                                                                      const int* __restrict__ ids, const float4* __restrict__ pos,
                                                                      const int* __restrict__ count, signed char* __restrict__ delta,
                                                                      int* __restrict__ emit_count, Sum4* __restrict__ sums,
@@ -261,10 +345,9 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
     for (int q = 0; q < kScanItems; ++q) {
         const int k = k0 + q;
         if (k >= n) break;
-        const unsigned long long key = keys[k];
-        const int d_next = (k + 1 < n) ? common_levels(key, keys[k + 1]) : edge_next;
-        const int d_prev = (k > 0) ? common_levels(keys[k - 1], key) : edge_prev;
-        if (d_next >= kLevels) atomicOr(flags, 1);  // two bodies share all 21 levels: too deep for this build
+        const int d_next = (k + 1 < n) ? common_levels2(keys, keys2, k, k + 1) : edge_next;
+        const int d_prev = (k > 0) ? common_levels2(keys, keys2, k - 1, k) : edge_prev;
+        if (d_next >= 2 * kLevels) atomicOr(flags, 1);  // two bodies share all 42 levels: too deep for this build
         delta[k] = (signed char)d_next;
         const int ec = max(0, d_next - d_prev) + 1;  // opened cells + the leaf
         emit_count[k] = ec;
@@ -280,7 +363,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
 // base[k] = exclusive scan of emit_count, incl[k] = inclusive scan of the Sum4 terms
 __global__ __launch_bounds__(kScanThreads) void k_tree_scan(const int* __restrict__ emit_count, const Sum4* __restrict__ sums,
                                                             const int* __restrict__ count, const ScanItem* __restrict__ totals,
-                                                            int* __restrict__ base, Sum4* __restrict__ incl) {
+                                                            int* __restrict__ base, Sum4* __restrict__ incl, int* __restrict__ out_info) {
     __shared__ ScanItem lds[kScanThreads];
     __shared__ ScanItem carry_s;
     const int n = *count;
@@ -318,6 +401,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_scan(const int* __restric
         if (k0 + q < n) base[k0 + q] = run.c;
         run = item_add(run, item[q]);
         if (k0 + q < n) incl[k0 + q] = run.s;
+        if (k0 + q == n - 1) { out_info[0] = run.c; out_info[2] = n; }   // nodes in all; the live body count rides along (one read-back)
     }
 }
 
@@ -375,13 +459,13 @@ __global__ __launch_bounds__(256) void k_tree_own_scatter(const int* __restrict_
 
 size_t tree_build_workspace_bytes(size_t n_cap) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    return scratch_bytes(n_cap) + 2 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
+    return scratch_bytes(n_cap) + 3 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
 }
 
 namespace {
 struct BuildLayout {
     void* tmp; size_t tmp_bytes;
-    unsigned long long *keys_in, *keys;
+    unsigned long long *keys_in, *keys, *keys2;
     int *ids_in, *ids, *emit_count, *base;
     signed char* delta;
     Sum4 *sums, *incl;
@@ -394,6 +478,7 @@ BuildLayout build_layout(void* workspace, size_t n_cap) {
     L.tmp = p; p += L.tmp_bytes;
     L.keys_in = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
     L.keys = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
+    L.keys2 = reinterpret_cast<unsigned long long*>(p); p += al(n_cap * 8);
     L.ids_in = reinterpret_cast<int*>(p); p += al(n_cap * 4);
     L.ids = reinterpret_cast<int*>(p); p += al(n_cap * 4);
     L.emit_count = reinterpret_cast<int*>(p); p += al(n_cap * 4);
@@ -409,38 +494,55 @@ BuildLayout build_layout(void* workspace, size_t n_cap) {
 int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
                    void* workspace, size_t n_cap, int* out_info, TreeDevWork* work) {
     const BuildLayout L = build_layout(workspace, n_cap);
-    work->keys = L.keys; work->delta = L.delta; work->base = L.base; work->ids = L.ids; work->incl = L.incl;
+    work->keys = L.keys; work->keys2 = L.keys2; work->delta = L.delta; work->base = L.base; work->ids = L.ids; work->incl = L.incl;
     const int n = n_upper;
     if (n <= 0) { (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s); return 0; }  // (k_tree_keys clears it otherwise)
     hipLaunchKernelGGL(k_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, n, center[0], center[1], center[2], width,
                        L.keys_in, L.ids_in, out_info);
     size_t tb = L.tmp_bytes;
     if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_tree_ties, dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width, L.keys,
+                       L.keys2, L.ids, out_info + 1, std::max(1, nbody_tree_max_tie));
     return 0;
 }
 
-// Second half: delta, scans, emit.  edge (device, 2 ints, may be null): levels the first / last sorted body shares with
-// its neighbour on another rank (spatial shards), see k_tree_delta_totals.
-int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
-                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge) {
+// Second half: delta and the scans (out_info[0] = nodes in all, out_info[2] = bodies), then the emit.  edge (device, 2
+// ints, may be null): levels the first / last sorted body shares with its neighbour on another rank (spatial shards), see
+// k_tree_delta_totals.
+int tree_scan_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info,
+                     const int* edge) {
     const BuildLayout L = build_layout(workspace, n_cap);
     const int n = n_upper;
-    if (n > 0) {
-        const int n_tiles = (n + kScanTile - 1) / kScanTile;
-        ScanItem* totals = static_cast<ScanItem*>(L.tmp);   // (the sort is done with its scratch)
-        hipLaunchKernelGGL(k_tree_delta_totals, dim3(n_tiles), dim3(kScanThreads), 0, s, L.keys, L.ids, pos, d_count, L.delta,
-                           L.emit_count, L.sums, out_info + 1, totals, edge);
-        hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, L.emit_count, L.sums, d_count, totals, L.base, L.incl);
-    }
-    // one thread per node; their number is known on the device only, so one per node the array can hold
-    // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
-    hipLaunchKernelGGL(k_tree_emit, dim3((std::max(1, node_cap) + 255) / 256), dim3(256), 0, s, L.keys, L.ids, pos, d_count, L.delta,
-                       L.base, L.incl, width, nodes, node_cap, order, out_info, want_hot, edge);
+    if (n <= 0) return 0;
+    const int n_tiles = (n + kScanTile - 1) / kScanTile;
+    ScanItem* totals = static_cast<ScanItem*>(L.tmp);   // (the sort is done with its scratch)
+    hipLaunchKernelGGL(k_tree_delta_totals, dim3(n_tiles), dim3(kScanThreads), 0, s, L.keys, L.keys2, L.ids, pos, d_count, L.delta,
+                       L.emit_count, L.sums, out_info + 1, totals, edge);
+    hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, L.emit_count, L.sums, d_count, totals, L.base, L.incl, out_info);
     return 0;
+}
+// node_offset (device, may be null): the slice is written at nodes[*node_offset ..] with its links shifted; parent /
+// depth (may be null): per node of the slice, see k_tree_emit
+int tree_emit_nodes(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
+                    float4* nodes, int node_cap, int slice_cap, int* order, int* out_info, int want_hot, const int* edge,
+                    const int* node_offset, int* parent, unsigned char* depth) {
+    const BuildLayout L = build_layout(workspace, n_cap);
+    (void)n_upper;
+    // one thread per node; their number is known on the device only, so one per node the slice can have
+    // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
+    hipLaunchKernelGGL(k_tree_emit, dim3((std::max(1, slice_cap) + 255) / 256), dim3(256), 0, s, L.keys, L.keys2, L.ids, pos, d_count, L.delta,
+                       L.base, L.incl, width, nodes, node_cap, order, out_info, want_hot, edge, node_offset, parent, depth);
+    return 0;
+}
+int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
+                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge) {
+    if (tree_scan_sorted(s, pos, d_count, n_upper, workspace, n_cap, out_info, edge) != 0) return -1;
+    return tree_emit_nodes(s, pos, d_count, n_upper, width, workspace, n_cap, nodes, node_cap, node_cap, order, out_info, want_hot, edge,
+                           nullptr, nullptr, nullptr);
 }
 
 // Enqueues the whole build on `s`.  out_info (device, 3 ints): [0] = node count, [1] = flags, [2] = bodies in the tree
-// (1: deeper than 21 levels, 2: node_cap too small).  The caller reads it back before the walk.
+// (1: deeper than 42 levels, 2: node_cap too small).  The caller reads it back before the walk.
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
                         int* out_info, TreeDevWork* work, int want_hot) {
@@ -450,7 +552,7 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
 
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,
                            int* n_anc, int* anc, int max_anc, const int* info, int* poison) {
-    hipLaunchKernelGGL(k_tree_split_anc, dim3(n_split), dim3(32), 0, s, work.keys, work.delta, work.base, n, n_nodes,
+    hipLaunchKernelGGL(k_tree_split_anc, dim3(n_split), dim3(64), 0, s, work.keys, work.keys2, work.delta, work.base, n, n_nodes,
                        n_split, first, n_anc, anc, max_anc, info, poison);
 }
 

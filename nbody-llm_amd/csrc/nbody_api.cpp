@@ -336,12 +336,12 @@ int step_impl(NbodyHandle* h, float dt);
 extern "C" int nbody_bh_walk_debug;
 
 // strict math with the reference leaf rule walks with the reference's nested sums (bit-exact): per own body a stack
-// of the open cells on its path, 16 bytes each -- as many levels as the tree is deep (the device build stops at 21;
+// of the open cells on its path, 16 bytes each -- as many levels as the tree is deep (the device build stops at 42;
 // the host build reports its depth), not NBODY_MAX_TREE_DEPTH of them (13 GB at N = 2^22)
 int ensure_nested_stack(NbodyHandle* h, nbody::TreeDev* td) {
     if (h->cfg.math_mode != NBODY_MATH_STRICT || h->cfg.leaf_mode != NBODY_LEAF_REFERENCE) return NBODY_OK;
     const size_t lanes = (size_t(h->sh.seg_cap) + 255) / 256 * 256;
-    const int levels = (h->tree_on_device ? 22 : h->tree.max_depth) + 2;
+    const int levels = (h->tree_on_device ? 43 : h->tree.max_depth) + 2;   // (the device build goes to 42 levels)
     if (lanes > h->nested_cap || levels > h->nested_levels) {
         if (h->d_nested_stack) (void)hipFree(h->d_nested_stack);
         h->d_nested_stack = nullptr; h->nested_cap = 0; h->nested_levels = 0;
@@ -358,8 +358,8 @@ int ensure_nested_stack(NbodyHandle* h, nbody::TreeDev* td) {
 // fast math, variant 3: buffers of the LDS-staged walk and the threshold that picks the staged nodes.
 // Called after this step's first host synchronisation, so h_hot_info holds the previous pass's flagged count.
 int setup_lds_walk(NbodyHandle* h, nbody::TreeDev* td, size_t n_tree) {
-    // (its per-wave stack holds the 21 levels of the device build; a deeper host-built tree is walked by k_bh_walk)
-    if (h->cfg.math_mode == NBODY_MATH_FAST && nbody_bh_walk_variant == 5 && (h->tree_on_device || h->tree.max_depth <= 21)) {
+    // (its stack holds the 42 levels of the device build; a deeper host-built tree is walked by k_bh_walk)
+    if (h->cfg.math_mode == NBODY_MATH_FAST && nbody_bh_walk_variant == 5 && (h->tree_on_device || h->tree.max_depth <= 42)) {
         if (h->bfs_cap < h->d_node_cap) {
             if (h->d_bfs) (void)hipFree(h->d_bfs);
             if (h->d_bfs_ws) (void)hipFree(h->d_bfs_ws);
@@ -425,7 +425,7 @@ int bh_forces(NbodyHandle* h) {
         bool fell_back = false;
         rc = bh_walk_device_tree(h, &fell_back);
         if (rc || !fell_back) return rc;
-        // deeper than 21 levels somewhere: this step's tree comes from the host build below
+        // deeper than 42 levels somewhere: this step's tree comes from the host build below
     }
     h->host_tree_once = false;
     h->tree_on_device = false;
@@ -1452,6 +1452,7 @@ int nbody_reset_stats(NbodyHandle* h) {
     uint64_t nodes = h->stats.tree_nodes;
     h->stats = NbodyStats{};
     h->stats.tree_nodes = nodes;
+    if (h->let) { rc = nbody::let::reset_stats(h); if (rc) return rc; }
     if (h->f64) { rc = nbody64::reset_stats(h); if (rc) return rc; }
     else HIP_TRY(h, hipMemsetAsync(h->sh.inter, 0, sizeof(unsigned long long), h->stream));
     if (h->d_counters) {

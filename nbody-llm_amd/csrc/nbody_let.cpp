@@ -35,16 +35,15 @@ struct State {
     Migrant *d_send_mig = nullptr, *d_recv_mig = nullptr;   // [G][mig_cap]
     int *d_send_count = nullptr, *d_recv_count = nullptr;   // [G]
     int* d_new_count = nullptr;
-    int* d_flags = nullptr;       // [2] sticky flags (also the walk's poison word), step counter
-    int* d_box_ord = nullptr;     // [6]
+    int* d_flags = nullptr;       // [4] sticky flags (also the walk's poison word), step counter, bodies sent away so far
+    int* d_box_ord = nullptr;     // [(kBoxes + 1) * 6]
     EndInfo* d_ends = nullptr;    // [G]
     int* d_edge = nullptr;        // [3]
     RoundB* d_rb = nullptr;       // [G]
     int* d_offsets = nullptr;     // [G + 1]
     int* d_top_index = nullptr;   // [G][kLevels]
     int* d_split = nullptr;       // [4]: first[0] = 0, first[1] = total nodes, n_anc[0] = 0
-    float4* d_local = nullptr;    // own slice as the build emits it (local indices)
-    int local_cap = 0;            // nodes
+    int local_cap = 0;            // nodes a slice can have
     float4* d_global = nullptr;   // the global-index node array
     int global_cap = 0;
     int* d_order = nullptr;
@@ -54,9 +53,8 @@ struct State {
     int* d_parent = nullptr;
     unsigned char* d_depth = nullptr;
     unsigned int* d_upper_ok = nullptr;   // [kLevels]
-    unsigned int* d_node_flags = nullptr;
+    int2* d_node_flags = nullptr;   // per node of the slice: {its parent, the partners that could open it}
     int* d_let_count = nullptr;   // [G] nodes for each partner
-    int* d_let_cursor = nullptr;  // [G]
     LetRecord* d_let_send = nullptr;      // [G][let_stride]
     size_t let_stride = 0;
     LetRecord* d_let_recv = nullptr;
@@ -67,6 +65,8 @@ struct State {
     NbodyLetStats st{};
     size_t n_at_upload = 0;
     std::vector<int> recv_n;      // emulation / production: records received from each rank this pass
+    hipEvent_t ev[10] = {};       // begin/end of the five phases (nbody_set_profiling)
+    bool ev_made = false, ev_live = false;
 };
 
 namespace {
@@ -85,6 +85,18 @@ int fail(NbodyHandle* h, int code, const std::string& msg) { h->err = msg; retur
         if (r_ != ncclSuccess)                                                                        \
             return fail(h, NBODY_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));       \
     } while (0)
+
+// phase timing: an event at both ends of a phase, on the handle's stream; account() adds the five durations up
+struct PhaseTimer {
+    NbodyHandle* h; State& s; int phase;
+    PhaseTimer(NbodyHandle* h_, State& s_, int p) : h(h_), s(s_), phase(p) {
+        if (!h->profiling) { if (p == 0) s.ev_live = false; return; }
+        if (!s.ev_made) { for (hipEvent_t& e : s.ev) (void)hipEventCreate(&e); s.ev_made = true; }
+        if (p == 0) s.ev_live = true;
+        if (s.ev_live) (void)hipEventRecord(s.ev[2 * p], h->stream);
+    }
+    ~PhaseTimer() { if (h->profiling && s.ev_live) (void)hipEventRecord(s.ev[2 * phase + 1], h->stream); }
+};
 
 unsigned long long host_key(const float* p, const float c[3], float width) {   // kernels_tree.hip k_tree_keys on the host
     float cx = c[0], cy = c[1], cz = c[2];
@@ -111,11 +123,10 @@ int ensure_node_buffers(NbodyHandle* h, State& s) {
     const Shard& sh = h->sh;
     const int want_local = 4 * sh.seg_cap + 64;
     if (s.local_cap < want_local) {
-        for (void* p : {(void*)s.d_local, (void*)s.d_parent, (void*)s.d_depth, (void*)s.d_node_flags, (void*)s.d_let_send})
+        for (void* p : {(void*)s.d_parent, (void*)s.d_depth, (void*)s.d_node_flags, (void*)s.d_let_send})
             if (p) (void)hipFree(p);
-        s.d_local = nullptr; s.d_parent = nullptr; s.d_depth = nullptr; s.d_node_flags = nullptr; s.d_let_send = nullptr;
+        s.d_parent = nullptr; s.d_depth = nullptr; s.d_node_flags = nullptr; s.d_let_send = nullptr;
         int rc;
-        if ((rc = dev_alloc(h, &s.d_local, size_t(want_local) * 2))) return rc;
         if ((rc = dev_alloc(h, &s.d_parent, size_t(want_local)))) return rc;
         if ((rc = dev_alloc(h, &s.d_depth, size_t(want_local)))) return rc;
         if ((rc = dev_alloc(h, &s.d_node_flags, size_t(want_local)))) return rc;
@@ -146,16 +157,16 @@ int ensure_node_buffers(NbodyHandle* h, State& s) {
 // ---- the phases (everything is enqueued on h->stream; nothing here waits for the device)
 int phase0(NbodyHandle* h, State& s, float dt, bool drift) {
     Shard& sh = h->sh;
+    PhaseTimer timer(h, s, 0);
     int rc = ensure_node_buffers(h, s);
     if (rc) return rc;
     if (drift) {
         if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
         launch_drift_half(h->stream, sh, int(h->n_local), dt, h->bnd);   // integrate_pre_force
-        launch_compact(h->stream, sh, int(h->n_local));                  // retain
     }
     launch_classify(h->stream, sh, int(h->n_local), h->center, h->width, s.d_bounds, s.G, s.me, s.d_send_mig, s.d_send_count, s.mig_cap,
-                    s.d_flags);
-    launch_compact(h->stream, sh, int(h->n_local));                      // the emigrants leave
+                    s.d_flags, drift);
+    launch_compact(h->stream, sh, int(h->n_local));                      // retain, and the emigrants leave
     h->count_dirty = true;
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
@@ -163,21 +174,23 @@ int phase0(NbodyHandle* h, State& s, float dt, bool drift) {
 
 int phase1(NbodyHandle* h, State& s) {
     Shard& sh = h->sh;
+    PhaseTimer timer(h, s, 1);
     launch_append(h->stream, sh, s.d_recv_mig, s.d_recv_count, s.G, s.mig_cap, s.d_flags, s.d_new_count, s.d_send_count);
     // the host's bound of the own count: everything that could have arrived
     h->n_local = std::min<size_t>(size_t(sh.seg_cap), h->n_local + size_t(s.G) * size_t(s.mig_cap));
     if (tree_sort_keys(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->center, h->width, s.d_ws, s.ws_cap, s.d_tree_info, &s.work) != 0)
         return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
-    launch_ends(h->stream, sh, int(h->n_local), s.work.keys, s.d_box_ord, s.d_ends + s.me);
+    launch_ends(h->stream, sh, int(h->n_local), s.work.keys, s.work.ids, s.d_box_ord, s.d_ends + s.me);
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
 
 int phase2(NbodyHandle* h, State& s) {
     Shard& sh = h->sh;
+    PhaseTimer timer(h, s, 2);
     launch_edges(h->stream, s.d_ends, s.G, s.me, s.d_edge);
-    if (tree_emit_sorted(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->width, s.d_ws, s.ws_cap, s.d_local, s.local_cap, s.d_order,
-                         s.d_tree_info, 0, s.d_edge) != 0)
+    // delta, the scans: how many nodes my slice has, every body's first node, the prefix sums the spanning cells need
+    if (tree_scan_sorted(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), s.d_ws, s.ws_cap, s.d_tree_info, s.d_edge) != 0)
         return fail(h, NBODY_ERR_HIP, "device octree build failed");
     launch_contrib(h->stream, sh, s.work, s.d_tree_info, s.d_ends, s.d_edge, s.G, s.me, s.d_rb + s.me);
     HIP_TRY(h, hipGetLastError());
@@ -186,13 +199,16 @@ int phase2(NbodyHandle* h, State& s) {
 
 int phase3(NbodyHandle* h, State& s) {
     Shard& sh = h->sh;
+    PhaseTimer timer(h, s, 3);
     HIP_TRY(h, hipMemsetAsync(s.d_let_count, 0, sizeof(int) * s.G, h->stream));
-    HIP_TRY(h, hipMemsetAsync(s.d_let_cursor, 0, sizeof(int) * s.G, h->stream));
-    launch_finalize(h->stream, s.d_local, s.local_cap, s.d_tree_info, s.d_rb, s.d_ends, s.G, s.me, h->width, s.d_global, s.global_cap, s.d_offsets,
-                    s.d_top_index, s.d_flags);
-    launch_flags_and_pack(h->stream, sh, s.work, s.local_cap, s.d_tree_info, s.d_edge, s.d_global, s.d_offsets, s.d_top_index, s.d_ends, s.G, s.me,
-                          h->theta2, s.d_parent, s.d_depth, s.d_upper_ok, s.d_node_flags, s.d_let_count, s.d_let_send, s.let_stride,
-                          s.d_let_cursor, s.prune);
+    launch_offsets(h->stream, s.d_rb, s.G, s.global_cap, s.d_offsets, s.d_flags);
+    // my slice, straight to its place in the global-index array
+    if (tree_emit_nodes(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->width, s.d_ws, s.ws_cap, s.d_global, s.global_cap, s.local_cap,
+                        s.d_order, s.d_tree_info, 0, s.d_edge, s.d_offsets + s.me, s.d_parent, s.d_depth) != 0)
+        return fail(h, NBODY_ERR_HIP, "device octree build failed");
+    launch_finalize(h->stream, s.d_rb, s.d_ends, s.G, s.me, h->width, s.d_global, s.global_cap, s.d_offsets, s.d_top_index);
+    launch_flags_and_pack(h->stream, s.local_cap, s.d_tree_info, s.d_edge, s.d_global, s.d_offsets, s.d_top_index, s.d_ends, s.G, s.me, h->theta2,
+                          s.d_parent, s.d_depth, s.d_upper_ok, s.d_node_flags, s.d_let_count, s.d_let_send, s.let_stride, s.prune);
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
@@ -201,6 +217,7 @@ int phase3(NbodyHandle* h, State& s) {
 struct SplitInit { int first0, first1, n_anc0, pad; };
 int phase4(NbodyHandle* h, State& s, float dt, bool kick) {
     Shard& sh = h->sh;
+    PhaseTimer timer(h, s, 4);
     // first[] of the unsplit walk: {0, total}; the total lives on the device (offsets[G])
     HIP_TRY(h, hipMemsetAsync(s.d_split, 0, 4 * sizeof(int), h->stream));
     HIP_TRY(h, hipMemcpyAsync(s.d_split + 1, s.d_offsets + s.G, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
@@ -246,11 +263,12 @@ int create(NbodyHandle* h) {
     if ((rc = dev_alloc(h, &s.d_send_count, size_t(s.G)))) return rc;
     if ((rc = dev_alloc(h, &s.d_recv_count, size_t(s.G)))) return rc;
     if ((rc = dev_alloc(h, &s.d_new_count, 1))) return rc;
-    if ((rc = dev_alloc(h, &s.d_flags, 2))) return rc;
-    if ((rc = dev_alloc(h, &s.d_box_ord, 6))) return rc;
+    if ((rc = dev_alloc(h, &s.d_flags, 4))) return rc;
+    if ((rc = dev_alloc(h, &s.d_box_ord, (kBoxes + 1) * 6))) return rc;
     {
-        int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, int(0x80000000), int(0x80000000), int(0x80000000)};
-        HIP_TRY(h, hipMemcpyAsync(s.d_box_ord, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+        std::vector<int> init((kBoxes + 1) * 6);
+        for (size_t t = 0; t < init.size(); ++t) init[t] = (t % 6) < 3 ? 0x7fffffff : int(0x80000000);
+        HIP_TRY(h, hipMemcpyAsync(s.d_box_ord, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     if ((rc = dev_alloc(h, &s.d_ends, size_t(s.G)))) return rc;
@@ -262,7 +280,6 @@ int create(NbodyHandle* h) {
     if ((rc = dev_alloc(h, &s.d_tree_info, 4))) return rc;
     if ((rc = dev_alloc(h, &s.d_upper_ok, kLevels))) return rc;
     if ((rc = dev_alloc(h, &s.d_let_count, size_t(s.G)))) return rc;
-    if ((rc = dev_alloc(h, &s.d_let_cursor, size_t(s.G)))) return rc;
     if ((rc = dev_alloc(h, &s.d_let_matrix, size_t(s.G) * s.G))) return rc;
     if ((rc = dev_alloc(h, &h->sh.ids, size_t(h->sh.seg_cap)))) return rc;
     HIP_TRY(h, hipHostMalloc(&s.h_pin, (size_t(s.G) * s.G + 64) * sizeof(int), hipHostMallocDefault));
@@ -275,13 +292,14 @@ void destroy(NbodyHandle* h) {
     State* s = h->let;
     if (!s) return;
     void* dev[] = {s->d_bounds, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_recv_count, s->d_new_count, s->d_flags, s->d_box_ord,
-                   s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_local, s->d_global, s->d_order, s->d_tree_info,
-                   s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_cursor, s->d_let_send,
+                   s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_global, s->d_order, s->d_tree_info,
+                   s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_send,
                    s->d_let_recv, s->d_let_matrix, h->sh.ids};
     for (void* p : dev) if (p) (void)hipFree(p);
     h->sh.ids = nullptr;
     h->sh.poison = nullptr;
     if (s->h_pin) (void)hipHostFree(s->h_pin);
+    if (s->ev_made) for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
     h->let = nullptr;
 }
@@ -331,7 +349,7 @@ int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     HIP_TRY(h, hipMemsetAsync(sh.escaped, 0, sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d_send_count, 0, sizeof(int) * s.G, h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d_recv_count, 0, sizeof(int) * s.G, h->stream));
-    HIP_TRY(h, hipMemsetAsync(s.d_flags, 0, 2 * sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d_flags, 0, 4 * sizeof(int), h->stream));
     h->n_local = m;
     h->seg_count_host[0] = int(m);
     h->h_counts[0] = int(m);
@@ -363,7 +381,7 @@ int check_flags(NbodyHandle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int f = s.h_pin[0];
     if (!f) return NBODY_OK;
-    if (f & (kFlagDeep)) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 21 levels");
+    if (f & (kFlagDeep)) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 42 levels (coincident?)");
     if (f & kFlagMigOverflow) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: more bodies migrate to one rank in a step than NBODY_LET_MIG_CAP");
     if (f & kFlagCapacity) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: a rank's capacity is exhausted by immigrants");
     if (f & (kFlagNodeCap | kFlagNodeCapLocal)) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: node array too small");
@@ -385,11 +403,18 @@ int stats(NbodyHandle* h, NbodyLetStats* out) {
     return NBODY_OK;
 }
 
+int reset_stats(NbodyHandle* h) {
+    h->let->st = NbodyLetStats{};
+    HIP_TRY(h, hipMemsetAsync(h->let->d_flags + 2, 0, sizeof(int), h->stream));
+    return NBODY_OK;
+}
+
 // bookkeeping after a pass: read the small numbers back (the pass is over: the caller synchronises anyway)
 static int account(NbodyHandle* h, State& s) {
     HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_let_count, sizeof(int) * s.G, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(s.h_pin + 16, s.d_offsets, sizeof(int) * (s.G + 1), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(s.h_pin + 40, s.d_tree_info, sizeof(int) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_pin + 44, s.d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     uint64_t sent = 0;
     for (int r = 0; r < s.G; ++r) sent += uint64_t(std::max(0, s.h_pin[r]));
@@ -406,6 +431,12 @@ static int account(NbodyHandle* h, State& s) {
     uint64_t rec = 0;
     for (int n : s.recv_n) rec += uint64_t(n);
     s.st.nodes_received += rec;
+    s.st.bodies_migrated = uint64_t(std::max(0, s.h_pin[44]));
+    if (h->profiling && s.ev_live)
+        for (int p = 0; p < 5; ++p) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.ev[2 * p], s.ev[2 * p + 1]) == hipSuccess) s.st.phase_ms[p] += double(ms);
+        }
     return NBODY_OK;
 }
 

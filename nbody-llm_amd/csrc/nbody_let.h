@@ -16,6 +16,7 @@ int count_global(NbodyHandle* h, size_t* n_out);
 int step(NbodyHandle* h, float dt);         // one step with the RCCL exchanges
 int update_forces(NbodyHandle* h);
 int stats(NbodyHandle* h, NbodyLetStats* out);
+int reset_stats(NbodyHandle* h);
 int check_flags(NbodyHandle* h);            // turns the device's sticky flags into an error code (synchronises)
 // one-process emulation of G ranks (tests): the phases between the exchanges, and the exchanges as copies
 int debug_phase(NbodyHandle* h, int phase, float dt);

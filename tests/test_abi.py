@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(nb):
 def test_struct_layouts_match_the_header(nb):
     # uint32 + 7 x int32 + uint64 + 4 x int32 (48 bytes up to ABI 2, then shard_mode + reserved); 6 x uint64 + 4 x double
     assert ctypes.sizeof(nb.NbodyConfig) == 56
-    assert ctypes.sizeof(nb.NbodyLetStats) == 64
+    assert ctypes.sizeof(nb.NbodyLetStats) == 104
     assert nb.PARTICLE_DTYPE64.itemsize == 80
     assert ctypes.sizeof(nb.NbodyStats) == 80
     assert nb.PARTICLE_DTYPE.itemsize == 40

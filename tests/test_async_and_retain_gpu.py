@@ -64,7 +64,7 @@ def test_unsynchronised_steps_equal_synchronised_steps(gpu, math, n, box_w, chun
 
 
 def test_poisoned_run_is_replayed_from_the_failed_step(gpu, orc):
-    """Two bodies 2e-7 apart with the same velocity separate only below the device build's 21 levels, step after step:
+    """Two bodies 2e-7 apart with the same velocity separate only below the 21 levels of the device build's first keys (its second keys are switched off here), step after step:
     the build raises its flag ON THE DEVICE, every later kernel of the 6 enqueued steps does nothing, and at the next
     synchronisation point the host finishes the failed step with the host build and enqueues the rest again -- which
     fails again, and so on.  Every step thus runs on the host-built tree: the run equals the strict oracle's, bit for
@@ -75,8 +75,14 @@ def test_poisoned_run_is_replayed_from_the_failed_step(gpu, orc):
     ics = nb.plummer(500, seed=3)
     ics["position"][7] = ics["position"][3] + np.float32(2e-7)
     ics["velocity"][7] = ics["velocity"][3]
-    a, sa, ea, _ = run(nb, ics, BOX, st, nb.STRICT, 6, True)
-    b, sb, eb, _ = run(nb, ics, BOX, st, nb.STRICT, 6, False)
+    import ctypes
+    tie = ctypes.c_int.in_dll(nb.lib, "nbody_tree_max_tie")
+    tie.value = 1   # (no second keys: any collision of the 63-bit keys is "too deep", as a group of > 64 would be)
+    try:
+        a, sa, ea, _ = run(nb, ics, BOX, st, nb.STRICT, 6, True)
+        b, sb, eb, _ = run(nb, ics, BOX, st, nb.STRICT, 6, False)
+    finally:
+        tie.value = 64
     assert ea == eb and sa.steps == sb.steps == 6
     ref = ics.copy().astype(orc.P32)
     tot_a = tot_v = 0
@@ -106,11 +112,14 @@ def test_poison_in_the_middle_of_a_run(gpu):
     import ctypes
     spl = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
     spl.value = 4
+    tie = ctypes.c_int.in_dll(nb.lib, "nbody_tree_max_tie")
+    tie.value = 1   # (no second keys: the collision poisons the run)
     try:
         a, sa, ea, _ = run(nb, ics, BOX, st, nb.FAST, 10, True)
         b, sb, eb, _ = run(nb, ics, BOX, st, nb.FAST, 10, False)
     finally:
         spl.value = 0
+        tie.value = 64
     # the encounter did happen below level 21: replay the straight lines in float32
     x4, x9 = ics["position"][4].copy(), ics["position"][9].copy()
     h9 = (ics["velocity"][9] * np.float32(0.5)) * np.float32(1e-2)

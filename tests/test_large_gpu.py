@@ -165,3 +165,47 @@ def test_barnes_hut_four_million_bodies_in_eight_shards(gpu):
         assert np.array_equal(got[f], ref[f]), f
     assert sum(s.interactions for s in stats) == s1.interactions and sum(s.node_visits for s in stats) == s1.node_visits
     assert all(s.tree_nodes == s1.tree_nodes for s in stats)
+
+
+def test_barnes_hut_four_million_bodies_in_eight_spatial_shards(gpu):
+    """configs[4] the way it scales (option B of SURVEY section 8e): every rank owns a key range of ~524 288 bodies,
+    builds only its slice of the tree and imports the nodes its bodies can reach.  Eight handles on this device, the four
+    exchanges as device-to-device copies.  Two steps against the single-handle device-tree run: the assembled tree has the
+    same nodes, forces agree to rounding (a last-bit difference in a centre of mass flips the odd opening test), and the
+    records a rank sends are a small fraction of what replicating every position costs."""
+    nb = gpu
+    n, G = 1 << 22, 8
+    st = nb.Settings(1.0, 1e-2, 1e-3, 0.25)
+    ics = nb.plummer(n, seed=13)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as one:
+        one.settings = st
+        one.init()
+        one.steps(2)
+        ref = one.get_points()
+        s1 = one.stats()
+    sims = [nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, rank=r, world_size=G, capacity=n,
+                          shard_mode=nb.SHARD_SPATIAL) for r in range(G)]
+    for s in sims:
+        s.settings = st
+        s.init()
+    for _ in range(2):
+        nb.spatial_step(sims)
+    got, idx = nb.spatial_gather(sims, n)
+    stats = [s.stats() for s in sims]
+    ls = [s.let_stats() for s in sims]
+    owned = [len(s) for s in sims]
+    for s in sims:
+        s.close()
+    assert np.array_equal(idx, np.arange(n)) and len(ref) == n
+    assert all(s.tree_nodes == s1.tree_nodes for s in stats)
+    assert max(owned) - min(owned) < 0.02 * n / G                       # the key-range quantiles still balance
+    assert abs(sum(s.interactions for s in stats) - s1.interactions) < 1e-5 * s1.interactions
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
+    err = np.abs(got["acceleration"].astype(np.float64) - ref["acceleration"]).max(axis=1) / np.abs(ref["acceleration"]).max()
+    assert np.quantile(err, 0.9999) < 1e-5 and err.max() < 1e-2, (np.quantile(err, 0.9999), err.max())
+    sent = sum(l.bytes_sent for l in ls)
+    naive = sum(l.bytes_allgather_equivalent for l in ls)
+    print(f"2^22 bodies, 8 spatial shards, 2 steps: {sent / 2 / G / 1e6:.2f} MB sent per rank per step against "
+          f"{naive / 2 / G / 1e6:.2f} MB for the all-gather of positions ({sent / naive:.1%}); nodes per rank "
+          f"{[l.nodes_local // 2 for l in ls]}, imported {[l.nodes_received // 2 for l in ls]}")
+    assert sent < 0.5 * naive

@@ -152,6 +152,42 @@ def test_spatial_forces_equal_the_single_shard_device_tree(gpu, orc, G, n, leaf,
         assert all(l.nodes_local * (G - 1) - 21 * (G - 1) <= l.nodes_sent <= l.nodes_local * (G - 1) for l in ls)
 
 
+def test_spatial_shards_with_bodies_that_share_all_21_levels(gpu):
+    """Groups of bodies a few 1e-7 apart (equal 63-bit keys: always on one rank) get the device build's second keys in
+    the distributed build too; without them (nbody_tree_max_tie = 1) the step is refused, there being no host build to
+    fall back to."""
+    import ctypes
+    nb = gpu
+    n, G = 6000, 3
+    st = nb.Settings(1.0, 0.01, 1e-3, 0.25)
+    ics = nb.plummer(n, seed=66)
+    rng = np.random.default_rng(1)
+    for dst, src in ((1, 0), (7, 3), (11, 3), (n - 1, n // 2), (100, 99), (101, 99), (102, 99), (103, 99)):
+        ics["position"][dst] = ics["position"][src] + rng.integers(1, 12, 3).astype(np.float32) * np.float32(1.2e-7)
+    sims = make_world(nb, ics, G, BOX, st)
+    nb.spatial_step(sims, forces_only=True)
+    rec, idx = nb.spatial_gather(sims, n)
+    stats = [s.stats() for s in sims]
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as one:
+        one.settings = st
+        one.update_forces()
+        ref = one.get_points()
+        s1 = one.stats()
+        width = one.tree()["width"]
+    assert np.log2(BOX[1] / np.float64(width.min())) > 22
+    assert all(s.tree_nodes == s1.tree_nodes for s in stats)
+    assert_same_up_to_flips(rec["acceleration"], ref["acceleration"], 2e-6)
+    tie = ctypes.c_int.in_dll(nb.lib, "nbody_tree_max_tie")
+    tie.value = 1
+    try:
+        with pytest.raises(nb.NbodyError) as e:
+            nb.spatial_step(sims, forces_only=True)
+        assert e.value.code == nb.NBODY_ERR_TREE_DEPTH
+    finally:
+        tie.value = 64
+        close(sims)
+
+
 def test_pruning_changes_the_volume_not_the_result(gpu):
     nb = gpu
     n, G = 20000, 4
