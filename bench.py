@@ -74,6 +74,9 @@ def parse():
                     help="--workload bh: octree build on the host (north_star, bit-exact) or on the device (SURVEY F3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bh", action="store_true", help="default line without the configs[2] object")
+    ap.add_argument("--spatial-n", type=int, default=1 << 22, help="N > 1 GPUs: bodies of the configs[4] object (0: leave it out)")
+    ap.add_argument("--spatial-steps", type=int, default=10)
+    ap.add_argument("--spatial-timeout", type=float, default=300.0, help="seconds before the configs[4] object is given up")
     ap.add_argument("--seed", type=int, default=20250523)
     return ap.parse_args()
 
@@ -227,6 +230,36 @@ def run(nb, args, workload, tree, ics, box, st, rank, world, local_rank, dist, i
     return elapsed, stats, n_after
 
 
+def run_spatial(nb, args, box, st, rank, world, local_rank, dist, ident_fn):
+    """configs[4]: Barnes-Hut over spatial shards with the halo exchange of nodes (NBODY_SHARD_SPATIAL, nbody_let.cpp),
+    one rank per GPU over RCCL.  Returns this rank's record."""
+    n = args.spatial_n
+    ics = nb.plummer(n, seed=args.seed)
+    sim = nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, capacity=n, device=local_rank, rank=rank, world_size=world,
+                        shard_mode=nb.SHARD_SPATIAL)
+    sim.settings = nb.Settings(**st)
+    sim.comm_init(ident_fn())
+    sim.init()
+    sim.steps(2)
+    sim.set_profiling(True)
+    sim.reset_stats()
+    sim.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    sim.steps(args.spatial_steps)
+    sim.sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats, ls = sim.stats(), sim.let_stats()
+    own = len(sim)
+    sim.close()
+    k = float(max(1, ls.steps))
+    return {"elapsed": elapsed, "interactions": float(stats.interactions), "visits": float(stats.node_visits), "tree_nodes": int(stats.tree_nodes),
+            "bodies": own, "nodes_local": ls.nodes_local / k, "nodes_sent": ls.nodes_sent / k, "nodes_received": ls.nodes_received / k,
+            "bytes_sent": ls.bytes_sent / k, "bytes_allgather": ls.bytes_allgather_equivalent / k, "migrated": ls.bodies_migrated / k,
+            "phase_ms": [ls.phase_ms[i] / k for i in range(5)]}
+
+
 def bh_record(args, n, tree, elapsed, stats):
     visits = float(stats.node_visits)
     launches = float(stats.force_launches)
@@ -345,6 +378,51 @@ def main():
             bh[f"{tree}_tree"] = bh_record(args, n, tree, e2, s2)
         if rank == 0:
             result["bh"] = bh
+
+    # configs[4] beside the metric's line when there is more than one GPU: Barnes-Hut over spatial shards.  Its RCCL
+    # exchange runs with > 1 rank only here (a one-GPU box cannot rehearse it), so it is fenced: an error or a rank that
+    # does not come back within --spatial-timeout leaves a note in the line instead of taking the metric with it.
+    if args.workload == "bf" and world > 1 and not args.no_bh and args.spatial_n > 0:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                result["bh_spatial"] = {"error": f"no result within {args.spatial_timeout:.0f} s"}
+                result["cpu_baseline"] = None
+                os.write(json_fd if json_fd is not None else 1, (json.dumps(result) + "\n").encode())
+            os._exit(0)
+
+        guard = threading.Timer(args.spatial_timeout, give_up)
+        guard.daemon = True
+        guard.start()
+        rec = None
+        try:
+            rec = run_spatial(nb, args, box, dict(st, theta2=theta2), rank, world, local_rank, dist, ident_fn)
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the metric's line must still go out
+            rec = {"error": f"{type(e).__name__}: {e}"}
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+        guard.cancel()
+        if rank == 0:
+            bad = [r for r in recs if r is None or "error" in r]
+            if bad:
+                result["bh_spatial"] = {"error": (bad[0] or {}).get("error", "a rank returned nothing")}
+            else:
+                el = max(r["elapsed"] for r in recs)
+                k = args.spatial_steps
+                result["bh_spatial"] = {
+                    "workload": f"configs[4]: {args.spatial_n}-body Barnes-Hut theta={args.theta}, {world} spatial shards (Morton-key ranges), "
+                                "halo exchange of tree nodes over RCCL",
+                    "ms_per_step": 1e3 * el / k, "steps_per_sec": k / el, "interactions_per_sec": sum(r["interactions"] for r in recs) / el,
+                    "tree_nodes": recs[0]["tree_nodes"], "steps": k,
+                    "per_rank": [{kk: r[kk] for kk in ("bodies", "nodes_local", "nodes_sent", "nodes_received", "bytes_sent", "bytes_allgather",
+                                                       "migrated", "phase_ms")} for r in recs],
+                    "phase_names": ["drift+retain+pick migrants", "append+keys+sort", "scans+spanning-cell table", "emit+flag+pack export",
+                                    "walk+kick"],
+                    "note": "phase_ms = device time of each rank's kernels between the exchanges (HIP events); the exchanges themselves are in ms_per_step only",
+                    "parity": "fast math, device build: node counts equal the single-GPU tree's, accelerations to rounding (tests/test_spatial_gpu.py, "
+                              "tests/test_large_gpu.py at this size, one-GPU emulation of the ranks)",
+                }
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
