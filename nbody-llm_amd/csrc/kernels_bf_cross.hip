@@ -21,6 +21,11 @@
 #include <algorithm>
 
 extern "C" int nbody_sym_packed;
+// tuning knobs of the plan (tools/tune_sharded.py); every rank of a world must use the same values
+extern "C" int nbody_cross_slots = 3072;  // waves the chunk visits are dealt to
+extern "C" int nbody_cross_ipt = 0;       // resident bodies per lane: 0 = by the rule below, 4, 8
+extern "C" int nbody_cross_wpb = 4;       // waves per workgroup: 4, 8, 12 (4: three times as many workgroups as CUs, dealt evenly;
+                                          // 12 = one workgroup per CU left CUs idle: G = 8, N = 65 536: 0.100 against 0.114 ms)
 
 namespace nbody {
 
@@ -157,11 +162,12 @@ __global__ __launch_bounds__(256) void k_bf_cross_reduce(const float4* __restric
 CrossPlan make_cross_plan(int rank, int G, int seg_cap, int n_own_upper) {
     CrossPlan p;
     // resident sets of 8 bodies per lane; 4 when the shards are small: a chunk visit is the unit of work
-    // and with few sets there are too few visits per wave to deal them evenly.  Decided from the shard
+    // and with few sets there are too few visits per wave to deal them evenly (fewer than one per slot; at one to three
+    // per wave 8 with packed pairs is already ahead: G = 8, N = 65 536: 0.100 ms against 0.122 with 4).  Decided from the shard
     // CAPACITY, which every rank knows, so that all ranks cut the opposite-rank pair at the same chunk.
     const int chunks_cap = (seg_cap + 63) / 64;                 // chunks a shard can hold
     const long long visits8 = (long long)((seg_cap + 511) / 512) * chunks_cap * std::max(1, G / 2);
-    const int IPT = (visits8 < 4 * 3072) ? 4 : 8;
+    const int IPT = (nbody_cross_ipt == 4 || nbody_cross_ipt == 8) ? nbody_cross_ipt : (visits8 < 3072) ? 4 : 8;
     p.ipt = IPT;
     p.A = (n_own_upper + 64 * IPT - 1) / (64 * IPT);
     // opposite ranks: the lower rank takes the higher rank's chunks below `split`, the higher rank keeps
@@ -197,7 +203,7 @@ CrossPlan make_cross_plan(int rank, int G, int seg_cap, int n_own_upper) {
         for (int i = 0; i < q.n; ++i) if (a >= q.a0[i] && a < q.a1[i]) L[a] += q.c1[i] - q.c0[i];
         total += L[a];
     }
-    const int slots = 256 * 12;
+    const int slots = std::max(256, nbody_cross_slots);
     const double target = std::max(1.0, double(total) / double(slots));
     int kmax = 1;
     std::vector<int> Ka(p.A, 0);
@@ -219,14 +225,15 @@ CrossPlan make_cross_plan(int rank, int G, int seg_cap, int n_own_upper) {
 void launch_bf_cross(hipStream_t s, const Shard& sh, const CrossPlan& p, const int4* d_slices, float4* res_planes,
                      float4* xplanes, float4* send, size_t plane_stride, float g_soft2) {
     if (p.slices.empty() || p.parts.n == 0) return;
-    const int wpb = 12;
     const int n_slices = int(p.slices.size());
-#define CROSS_LAUNCH(IPT, PKV) hipLaunchKernelGGL((k_bf_cross<IPT, 12, PKV>), dim3((n_slices + wpb - 1) / wpb), dim3(wpb * 64), 0, s, sh.pos_all, sh.seg_count, sh.seg_cap, sh.my_seg, p.parts, d_slices, n_slices, p.A, res_planes, xplanes, plane_stride, g_soft2)
+#define CROSS_LAUNCH(IPT, WPB, PKV) hipLaunchKernelGGL((k_bf_cross<IPT, WPB, PKV>), dim3((n_slices + WPB - 1) / WPB), dim3(WPB * 64), 0, s, sh.pos_all, sh.seg_count, sh.seg_cap, sh.my_seg, p.parts, d_slices, n_slices, p.A, res_planes, xplanes, plane_stride, g_soft2)
+#define CROSS_LAUNCH_W(IPT, PKV) do { if (nbody_cross_wpb == 4) CROSS_LAUNCH(IPT, 4, PKV); else if (nbody_cross_wpb == 8) CROSS_LAUNCH(IPT, 8, PKV); else CROSS_LAUNCH(IPT, 12, PKV); } while (0)
     // packed pairs only with 8 bodies per lane: with 4 a stage is two instructions long and the dependent
     // stages stall on each other (G = 8 at N = 65 536: 0.140 ms packed, 0.119 ms scalar)
-    if (p.ipt == 4) CROSS_LAUNCH(4, false);
-    else if (nbody_sym_packed) CROSS_LAUNCH(8, true);
-    else CROSS_LAUNCH(8, false);
+    if (p.ipt == 4) CROSS_LAUNCH_W(4, false);
+    else if (nbody_sym_packed) CROSS_LAUNCH_W(8, true);
+    else CROSS_LAUNCH_W(8, false);
+#undef CROSS_LAUNCH_W
 #undef CROSS_LAUNCH
     hipLaunchKernelGGL(k_bf_cross_reduce, dim3((sh.seg_cap + 255) / 256, p.parts.n), dim3(256), 0, s, xplanes,
                        plane_stride, p.parts, p.A, sh.seg_cap, send);

@@ -391,12 +391,63 @@ __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict_
     }
 }
 
+// The same with Q waves per 64 bodies, each adding up a contiguous run of the planes (fixed split, fixed order: still
+// deterministic); wave 0 adds the Q partial sums.  One thread per body left a shard of 8 192 bodies with 32 workgroups
+// walking ~200 planes each: 70 us, the second-longest kernel of an 8-GPU step.
+template <bool KICK, int Q>
+__global__ __launch_bounds__(64 * Q) void k_bf_sym_reduce_split(const float4* __restrict__ planes, int n_planes, size_t plane_stride,
+                                                                const int* __restrict__ count, float g, float4* __restrict__ acc,
+                                                                float4* __restrict__ pos, float4* __restrict__ vel, float dt,
+                                                                const int* __restrict__ seg_count, int n_seg,
+                                                                unsigned long long* __restrict__ inter) {
+    __shared__ float part[Q][3][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    if (inter && blockIdx.x == 0 && threadIdx.x == 0) {   // NbodyStats::interactions of this force pass, from the live counts
+        long long tot = 0;
+        for (int s = 0; s < n_seg; ++s) tot += seg_count[s];
+        if (tot > 0) atomicAdd(inter, (unsigned long long)(*count) * (unsigned long long)(tot - 1));
+    }
+    const int n = *count;
+    float sx = 0.f, sy = 0.f, sz = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+    if (i < n) {
+        const int p0 = int((long long)n_planes * q / Q), p1 = int((long long)n_planes * (q + 1) / Q);
+        for (int p = p0; p < p1; ++p) {
+            const float4 v = planes[size_t(p) * plane_stride + i];
+            const float yx = v.x - cx, yy = v.y - cy, yz = v.z - cz;
+            const float tx = sx + yx, ty = sy + yy, tz = sz + yz;
+            cx = (tx - sx) - yx; cy = (ty - sy) - yy; cz = (tz - sz) - yz;
+            sx = tx; sy = ty; sz = tz;
+        }
+    }
+    part[q][0][lane] = sx; part[q][1][lane] = sy; part[q][2][lane] = sz;
+    __syncthreads();
+    if (q != 0 || i >= n) return;
+    sx = sy = sz = cx = cy = cz = 0.f;
+    for (int w = 0; w < Q; ++w) {
+        const float yx = part[w][0][lane] - cx, yy = part[w][1][lane] - cy, yz = part[w][2][lane] - cz;
+        const float tx = sx + yx, ty = sy + yy, tz = sz + yz;
+        cx = (tx - sx) - yx; cy = (ty - sy) - yy; cz = (tz - sz) - yz;
+        sx = tx; sy = ty; sz = tz;
+    }
+    const float4 a = make_float4(g * sx, g * sy, g * sz, 0.f);
+    acc[i] = a;
+    if (KICK) {
+        float4 p = pos[i], v = vel[i];
+        v.x += a.x * dt; v.y += a.y * dt; v.z += a.z * dt;
+        p.x += (v.x * 0.5f) * dt; p.y += (v.y * 0.5f) * dt; p.z += (v.z * 0.5f) * dt;
+        vel[i] = v;
+        pos[i] = p;
+    }
+}
+
 }  // namespace nbody
 namespace nbody { int read_sym_stamps(unsigned long long* out, int n_waves); }
 extern "C" int nbody_sym_read_stamps(unsigned long long* out, int n_waves) { return nbody::read_sym_stamps(out, n_waves); }
 extern "C" int nbody_sym_wpb = 12;     // waves per workgroup: 16, 12 or 8   (tuning hooks, tools/tune_sym.py)
 extern "C" int nbody_sym_rounds = 1;   // rounds of workgroups per CU
 extern "C" int nbody_sym_debug = 0;    // 4: diagnostic build with in-kernel cycle stamps
+extern "C" int nbody_sym_reduce_split = 1;   // 1: several waves per 64 bodies in the plane reduction; 0: one thread per body
 extern "C" int nbody_sym_packed = 1;   // 1: packed-fp32 pair evaluation (pair_evals_pk), 0: scalar; env NBODY_SYM_PACKED
 namespace nbody {
 
@@ -412,6 +463,7 @@ SymPlan make_sym_plan(int n_upper) {
     // SIMD), so the grid is dealt evenly; `rounds` > 1 makes shorter waves in several rounds, which
     // trims the tail at the price of more resident-side planes
     p.wpb = nbody_sym_wpb == 8 ? 8 : nbody_sym_wpb == 12 ? 12 : 16;
+    if (n_upper <= 8192 && nbody_sym_wpb == 12) p.wpb = 8;   // a small shard (8 GPUs at N = 65 536): one-chunk waves, smaller workgroups deal better (-9 us)
     const int resident_wgs_per_cu = (p.wpb == 8) ? 2 : 1;
     const int slots = 256 * resident_wgs_per_cu * p.wpb;  // waves the chip holds at once
     // A * K waves run in ceil(A*K/slots) rounds; pick the K (few, long slices preferred) whose last
@@ -506,13 +558,23 @@ void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4
         hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(),
                            sh.own_count(), p.A, planes + size_t(p.sym_sets + p.k_res) * p.plane_stride, g_soft2);
     }
-    const dim3 grid((n_upper + 255) / 256);
-    if (kick_dt)
-        hipLaunchKernelGGL(k_bf_sym_reduce<true>, grid, dim3(256), 0, s, planes, p.n_planes, p.plane_stride, sh.own_count(), g,
-                           sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.seg_count, sh.n_seg, sh.inter);
-    else
-        hipLaunchKernelGGL(k_bf_sym_reduce<false>, grid, dim3(256), 0, s, planes, p.n_planes, p.plane_stride, sh.own_count(), g,
-                           sh.acc, sh.own_pos(), sh.vel, 0.f, sh.seg_count, sh.n_seg, sh.inter);
+    const float dt = kick_dt ? *kick_dt : 0.f;
+#define REDUCE_ARGS planes, p.n_planes, p.plane_stride, sh.own_count(), g, sh.acc, sh.own_pos(), sh.vel, dt, sh.seg_count, sh.n_seg, sh.inter
+    if (nbody_sym_reduce_split && p.n_planes >= 16) {   // several waves per 64 bodies: 16 for small shards, 4 otherwise
+        const dim3 grid((n_upper + 63) / 64);
+        if (n_upper <= 16384) {
+            if (kick_dt) hipLaunchKernelGGL((k_bf_sym_reduce_split<true, 16>), grid, dim3(1024), 0, s, REDUCE_ARGS);
+            else hipLaunchKernelGGL((k_bf_sym_reduce_split<false, 16>), grid, dim3(1024), 0, s, REDUCE_ARGS);
+        } else {
+            if (kick_dt) hipLaunchKernelGGL((k_bf_sym_reduce_split<true, 4>), grid, dim3(256), 0, s, REDUCE_ARGS);
+            else hipLaunchKernelGGL((k_bf_sym_reduce_split<false, 4>), grid, dim3(256), 0, s, REDUCE_ARGS);
+        }
+    } else {
+        const dim3 grid((n_upper + 255) / 256);
+        if (kick_dt) hipLaunchKernelGGL(k_bf_sym_reduce<true>, grid, dim3(256), 0, s, REDUCE_ARGS);
+        else hipLaunchKernelGGL(k_bf_sym_reduce<false>, grid, dim3(256), 0, s, REDUCE_ARGS);
+    }
+#undef REDUCE_ARGS
 }
 
 }  // namespace nbody

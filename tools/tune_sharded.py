@@ -1,29 +1,52 @@
-"""Force-pass time of ONE shard of a world of G (rank 0; the other segments keep their uploaded
-positions), one-sided kernel variants.  Emulates what each GPU of a G-GPU run computes per step."""
-import ctypes, os, sys, time
+"""Force-pass time of ONE shard of a world of G (rank 0; the other segments keep their uploaded positions): what each
+GPU of a G-GPU run computes per step, on one device.  Sweeps the knobs of the cross-shard plan.
+
+    python tools/tune_sharded.py [n] [--g 8] [--ipt 0,4,8] [--slots 2048,3072,4096] [--wpb 4,12] [--steps 40]
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
+
+ap = argparse.ArgumentParser()
+ap.add_argument("n", nargs="?", type=int, default=65536)
+ap.add_argument("--g", default="1,2,4,8")
+ap.add_argument("--ipt", default="0")
+ap.add_argument("--slots", default="3072")
+ap.add_argument("--wpb", default="4")
+ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--sym-wpb", default="12", help="own-shard kernel: waves per workgroup (8, 12, 16)")
+ap.add_argument("--sym-rounds", default="1")
+a = ap.parse_args()
 nb = graft.load_package()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
-var = ctypes.c_int.in_dll(nb.lib, "nbody_bf_fast_variant")
-ics = nb.plummer(n)
-for G in (1, 2, 4, 8):
-    sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST, rank=0, world_size=G, capacity=n)
-    sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
-    for v in variants:
-        var.value = v
-        if G == 1 and v == 0:
-            pass
-        for _ in range(3):
-            nb.sharded_step([sim])
-        sim.sync(); sim.set_profiling(True); sim.reset_stats()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            nb.sharded_step([sim])
-        s = sim.stats()
-        wall = (time.perf_counter() - t0) / 20 * 1e3
-        print(f"G={G} n_own={n//G} variant {v}: force kernel {s.force_kernel_ms/s.force_launches:.4f} ms; step wall {wall:.4f} ms "
-              f"-> per-GPU {s.force_kernel_interactions/s.force_launches/(s.force_kernel_ms/s.force_launches)/1e9:.2f} T/s in-kernel")
-    sim.close()
-var.value = 0
+knob = {k: ctypes.c_int.in_dll(nb.lib, f"nbody_cross_{k}") for k in ("ipt", "slots", "wpb")}
+sym_wpb, sym_rounds = ctypes.c_int.in_dll(nb.lib, "nbody_sym_wpb"), ctypes.c_int.in_dll(nb.lib, "nbody_sym_rounds")
+ics = nb.plummer(a.n)
+for sw, sr in [(int(x), int(y)) for x in a.sym_wpb.split(",") for y in a.sym_rounds.split(",")]:
+  sym_wpb.value, sym_rounds.value = sw, sr
+  for G in [int(x) for x in a.g.split(",")]:
+      for ipt in [int(x) for x in a.ipt.split(",")]:
+          for slots in [int(x) for x in a.slots.split(",")]:
+              for wpb in [int(x) for x in a.wpb.split(",")]:
+                  knob["ipt"].value, knob["slots"].value, knob["wpb"].value = ipt, slots, wpb
+                  sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST, rank=0, world_size=G, capacity=a.n)
+                  sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
+                  for _ in range(3):
+                      nb.sharded_step([sim])
+                  sim.sync(); sim.set_profiling(True); sim.reset_stats()
+                  t0 = time.perf_counter()
+                  for _ in range(a.steps):
+                      nb.sharded_step([sim])
+                  sim.sync()
+                  wall = (time.perf_counter() - t0) / a.steps * 1e3
+                  s = sim.stats()
+                  k_ms = s.force_kernel_ms / max(1, s.force_launches)
+                  print(f"sym_wpb={sw} rounds={sr} G={G} n_own={a.n // G} ipt={ipt} slots={slots} wpb={wpb}: dominant kernel {k_ms:.4f} ms "
+                        f"({s.force_kernel_interactions / max(1, s.force_launches) / max(k_ms, 1e-9) / 1e9:.2f} T inter/s), step wall {wall:.4f} ms", flush=True)
+                  sim.close()
+knob["ipt"].value, knob["slots"].value, knob["wpb"].value = 0, 3072, 4
+sym_wpb.value, sym_rounds.value = 12, 1
