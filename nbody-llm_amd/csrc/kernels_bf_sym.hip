@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_bf_sym_reduce(const float4* __restrict_
 
 // The same with Q waves per 64 bodies, each adding up a contiguous run of the planes (fixed split, fixed order: still
 // deterministic); wave 0 adds the Q partial sums.  One thread per body left a shard of 8 192 bodies with 32 workgroups
-// walking ~200 planes each: 70 us, the second-longest kernel of an 8-GPU step.
+// walking ~100 planes each: 44 us, the second-longest kernel of an 8-GPU step.
 template <bool KICK, int Q>
 __global__ __launch_bounds__(64 * Q) void k_bf_sym_reduce_split(const float4* __restrict__ planes, int n_planes, size_t plane_stride,
                                                                 const int* __restrict__ count, float g, float4* __restrict__ acc,

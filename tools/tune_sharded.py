@@ -21,10 +21,12 @@ ap.add_argument("--wpb", default="4")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--sym-wpb", default="12", help="own-shard kernel: waves per workgroup (8, 12, 16)")
 ap.add_argument("--sym-rounds", default="1")
+ap.add_argument("--reduce-split", type=int, default=1, help="0: the one-thread-per-body plane reduction of round 1")
 a = ap.parse_args()
 nb = graft.load_package()
 knob = {k: ctypes.c_int.in_dll(nb.lib, f"nbody_cross_{k}") for k in ("ipt", "slots", "wpb")}
 sym_wpb, sym_rounds = ctypes.c_int.in_dll(nb.lib, "nbody_sym_wpb"), ctypes.c_int.in_dll(nb.lib, "nbody_sym_rounds")
+ctypes.c_int.in_dll(nb.lib, "nbody_sym_reduce_split").value = a.reduce_split
 ics = nb.plummer(a.n)
 for sw, sr in [(int(x), int(y)) for x in a.sym_wpb.split(",") for y in a.sym_rounds.split(",")]:
   sym_wpb.value, sym_rounds.value = sw, sr
