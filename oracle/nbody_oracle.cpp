@@ -250,7 +250,9 @@ std::unique_ptr<OrthNode<F>> build_tree(const std::vector<const Body<F>*>& pts, 
             if (!orth[i].empty())
                 node->children[i] = build_tree<F>(orth[i], bounds.create_orthant(i), depth + 1, 0, too_deep);
     }
-    F mass = F(0);                                    // :174  Σ m in slice order
+    F mass = F(0);                                    // :174  Σ m in slice order (recent rustc folds float sums from -0.0, not
+                                                      // +0.0: the two differ only when every mass is -0.0, which no caller passes;
+                                                      // the vector sum of :175-178 is nalgebra's, folded from zeros())
     for (const Body<F>* p : pts) mass += p->mass;
     F s[3] = {F(0), F(0), F(0)};                      // :175-179  Σ (pos*m) in slice order, then / mass
     for (const Body<F>* p : pts)
