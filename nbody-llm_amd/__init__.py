@@ -68,6 +68,7 @@ DECLARED_SYMBOLS = [
     "nbody_set_settings_f64", "nbody_get_settings_f64", "nbody_set_bounds_f64", "nbody_step_by_f64", "nbody_elapsed_f64",
     "nbody_tree_export_f64", "nbody_ic_plummer_f64", "nbody_ic_disc_f64",
     "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
+    "nbody_debug_let_bounds",
 ]
 
 
@@ -157,6 +158,7 @@ _sig("nbody_let_stats", _i, _H, C.POINTER(NbodyLetStats))
 _sig("nbody_debug_let_phase", _i, _H, _i, _f)
 _sig("nbody_debug_let_exchange", _i, _H, _H, _i)
 _sig("nbody_debug_let_set_prune", _i, _H, _i)
+_sig("nbody_debug_let_bounds", _i, _H, C.c_void_p)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
 
@@ -245,6 +247,7 @@ class Simulation:
                  f64: bool | None = None, shard_mode: int = SHARD_INDEX, _handle=None, _f64: bool = False):
         self._h = _H()
         self.f64 = bool(_f64)
+        self.rank, self.world_size = int(rank), int(world_size)
         if _handle is not None:
             self._h = _handle
             return
@@ -409,6 +412,12 @@ class Simulation:
         s = NbodyLetStats()
         self._check(lib.nbody_let_stats(self._h, C.byref(s)))
         return s
+
+    def let_bounds(self) -> np.ndarray:
+        """NBODY_SHARD_SPATIAL: the key-range bounds the next classification uses ([world_size + 1] uint64)."""
+        out = np.zeros(self.world_size + 1, np.uint64)
+        self._check(lib.nbody_debug_let_bounds(self._h, out.ctypes.data))
+        return out
 
     def set_prune(self, on: bool):
         self._check(lib.nbody_debug_let_set_prune(self._h, int(bool(on))))

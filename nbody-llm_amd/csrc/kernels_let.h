@@ -8,7 +8,7 @@ namespace let {
 constexpr int kLevels = 21;     // levels of the device build's keys
 constexpr int kMaxRanks = 16;
 
-enum { kFlagDeep = 1, kFlagNodeCapLocal = 2, kFlagMigOverflow = 4, kFlagCapacity = 8, kFlagNodeCap = 16, kFlagLetOverflow = 32 };
+enum { kFlagDeep = 1, kFlagNodeCapLocal = 2, kFlagCapacity = 8, kFlagNodeCap = 16 };
 
 struct Migrant {                // a body on its way to the rank that owns its key range (64 bytes)
     float4 pos, vel, acc;
@@ -33,8 +33,10 @@ struct Contrib {                // [r][d]: what a rank adds to the cell of depth
                                 // r == self: index in its slice of the cell itself, -1 if the cell is not its own
 };
 
-struct RoundB {                 // what every rank tells the others after its local emit (all-gathered)
+struct RoundB {                 // what every rank tells the others after its scans (all-gathered)
     int n_nodes, flags, pad[2];
+    unsigned long long new_bound[kMaxRanks];   // [j]: the key at global sorted position j N / G if this rank holds it, else 0:
+                                               // next step's ownership bounds (the world's G-quantiles, redrawn every step)
     Contrib c[kMaxRanks][kLevels];
 };
 
@@ -43,15 +45,14 @@ struct LetRecord {              // an exported node (32 bytes): the record; b.z 
 };
 
 void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float center[3], float width, const unsigned long long* bounds,
-                     int G, int me, Migrant* send, int* send_count, int mig_cap, int* flags, bool after_drift);
-void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, const int* recv_count, int G, int mig_cap, int* flags,
-                   int* new_count, int* send_count);
+                     int G, int me, unsigned char* dest_of, Migrant* send, int* send_count, int* send_off, int* cursor, bool after_drift);
+void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, int n_in, int G, int* flags, int* new_count, int* send_count);
 void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
                  EndInfo* mine);
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge);
 void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
                     RoundB* mine);
-void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags);
+void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds);
 void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
                      const int* offsets, int* top_index);
 void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const int* edge, const float4* global_nodes, const int* offsets,

@@ -4,8 +4,8 @@
 // The tree is the one the single-shard device build makes (kernels_tree.hip: same cells, pre-order, skip links as
 // BarnesHutSimulation::build_tree, src/manual/barnes_hut.rs:143-183), but no rank ever sees all bodies:
 //   * ownership by Morton-key range: rank r holds the bodies whose 63-bit key (the orthant codes of 21 levels) lies in
-//     [bound[r], bound[r+1]); the bounds are the G-quantiles of the keys at upload.  Bodies that drift across a bound
-//     migrate (k_let_classify packs them per destination, k_let_append takes them in) -- a handful per step;
+//     [bound[r], bound[r+1]); the bounds are the G-quantiles of the world's keys, redrawn every step.  Bodies on the wrong side of a bound
+//     migrate (k_let_classify / k_let_pack_migrants pack them per destination, k_let_append takes them in);
 //   * then the GLOBAL sorted order is the concatenation of the ranks' local sorted orders, so in the build's
 //     formulation (body k opens the cells of depths delta[k-1]+1 .. delta[k]; its leaf sits at max(..)+1) only a rank's
 //     FIRST and LAST sorted body have a neighbour elsewhere: two "edge" values (k_let_edges) from an all-gather of every
@@ -70,52 +70,62 @@ __device__ __forceinline__ bool box_could_open(const float4 A, float w2, const f
     const float d2 = dx * dx + dy * dy + dz * dz;
     return !(w2 < theta2 * d2 * 0.9999f);
 }
-// ---- migration: a body whose key left this rank's range goes to the rank that owns it
-__global__ __launch_bounds__(256) void k_let_classify(const float4* __restrict__ pos, const float4* __restrict__ vel,
-                                                      const float4* __restrict__ acc, const int* __restrict__ ids,
-                                                      const int* __restrict__ count, float cx, float cy, float cz, float width,
-                                                      const unsigned long long* __restrict__ bounds, int G, int me,
-                                                      unsigned char* __restrict__ keep, int* __restrict__ escaped,
-                                                      Migrant* __restrict__ send, int* __restrict__ send_count, int mig_cap,
-                                                      int* __restrict__ flags, int after_drift) {
+// ---- migration: a body whose key left this rank's range goes to the rank that owns it.  Two passes, so that the
+// emigrants of each destination end up contiguous in ONE buffer of seg_cap records whatever their number (a thin disc
+// cut at z = 0 trades thousands of bodies per step between two ranks): classify + count, offsets, pack.
+__global__ __launch_bounds__(256) void k_let_classify(const float4* __restrict__ pos, const int* __restrict__ count, float cx, float cy,
+                                                      float cz, float width, const unsigned long long* __restrict__ bounds, int G, int me,
+                                                      unsigned char* __restrict__ keep, unsigned char* __restrict__ dest_of,
+                                                      int* __restrict__ escaped, int* __restrict__ send_count, int after_drift) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= *count) return;
+    dest_of[k] = 255;
     if (after_drift && !keep[k]) return;   // left the box in this step's drift: the retain pass below drops it with the emigrants
-    const float4 p = pos[k];
-    const unsigned long long key = key_of(p, cx, cy, cz, width);
+    const unsigned long long key = key_of(pos[k], cx, cy, cz, width);
     int dest = 0;   // last r with bounds[r] <= key
     for (int r = 1; r < G; ++r) if (bounds[r] <= key) dest = r;
     keep[k] = dest == me ? 1 : 0;      // (outside a step every flag is written here: the old ones belong to an earlier retain)
     if (dest == me) return;            // an emigrant leaves this rank: the retain pass (k_compact) closes the gap
+    dest_of[k] = (unsigned char)dest;
     atomicAdd(escaped, 1);
-    const int slot = atomicAdd(&send_count[dest], 1);
-    if (slot >= mig_cap) { atomicOr(flags, kFlagMigOverflow); return; }
+    atomicAdd(&send_count[dest], 1);
+}
+__global__ void k_let_mig_offsets(const int* __restrict__ send_count, int G, int* __restrict__ send_off, int* __restrict__ cursor) {
+    if (threadIdx.x != 0) return;
+    int run = 0;
+    for (int r = 0; r < G; ++r) { send_off[r] = run; run += send_count[r]; cursor[r] = 0; }
+    send_off[G] = run;
+}
+__global__ __launch_bounds__(256) void k_let_pack_migrants(const float4* __restrict__ pos, const float4* __restrict__ vel,
+                                                           const float4* __restrict__ acc, const int* __restrict__ ids,
+                                                           const int* __restrict__ count, const unsigned char* __restrict__ dest_of,
+                                                           const int* __restrict__ send_off, int* __restrict__ cursor,
+                                                           Migrant* __restrict__ send) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= *count) return;
+    const int dest = dest_of[k];
+    if (dest == 255) return;
+    const int slot = send_off[dest] + atomicAdd(&cursor[dest], 1);   // (<= the bodies this rank holds: the buffer has seg_cap records)
     Migrant m;
-    m.pos = p; m.vel = vel[k]; m.acc = acc[k]; m.id = ids[k]; m.pad[0] = m.pad[1] = m.pad[2] = 0;
-    send[size_t(dest) * mig_cap + slot] = m;
+    m.pos = pos[k]; m.vel = vel[k]; m.acc = acc[k]; m.id = ids[k]; m.pad[0] = m.pad[1] = m.pad[2] = 0;
+    send[slot] = m;
 }
 
-// received migrants (slot s: from rank s) behind the own bodies
+// received migrants (n_in of them, from whatever ranks) behind the own bodies
 __global__ __launch_bounds__(256) void k_let_append(float4* __restrict__ pos, float4* __restrict__ vel, float4* __restrict__ acc,
                                                     int* __restrict__ ids, int* __restrict__ count, int cap,
-                                                    const Migrant* __restrict__ recv, const int* __restrict__ recv_count, int G,
-                                                    int mig_cap, int* __restrict__ flags, int* __restrict__ new_count) {
+                                                    const Migrant* __restrict__ recv, int n_in, int* __restrict__ flags,
+                                                    int* __restrict__ new_count) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    int total = 0, src = -1, within = 0;
-    for (int s = 0; s < G; ++s) {
-        const int c = min(recv_count[s], mig_cap);
-        if (src < 0 && j < total + c) { src = s; within = j - total; }
-        total += c;
-    }
     const int n0 = *count;
     if (j == 0) {
-        if (n0 + total > cap) atomicOr(flags, kFlagCapacity);
-        *new_count = min(cap, n0 + total);   // (applied by k_let_commit_count: every thread of this launch reads the old count)
+        if (n0 + n_in > cap) atomicOr(flags, kFlagCapacity);
+        *new_count = min(cap, n0 + n_in);   // (applied by k_let_commit_count: every thread of this launch reads the old count)
     }
-    if (src < 0) return;
+    if (j >= n_in) return;
     const int d = n0 + j;
     if (d >= cap) return;
-    const Migrant m = recv[size_t(src) * mig_cap + within];
+    const Migrant m = recv[j];
     pos[d] = m.pos; vel[d] = m.vel; acc[d] = m.acc; ids[d] = m.id;
 }
 __global__ void k_let_commit_count(int* __restrict__ count, const int* __restrict__ new_count, int* __restrict__ send_count, int G,
@@ -193,6 +203,18 @@ __global__ __launch_bounds__(64) void k_let_contrib(const unsigned long long* __
     const int d = threadIdx.x;     // depth
     const int n = *count;
     if (r == 0 && d == 0) { mine->n_nodes = n > 0 ? info[0] : 0; mine->flags = info[1]; mine->pad[0] = mine->pad[1] = 0; }
+    if (r == 0 && d < kMaxRanks) {
+        // Next step's bounds.  The world's sorted order is the concatenation of the ranks' sorted orders, so its G-quantiles
+        // are plain look-ups: quantile j sits at global position j N / G, on the rank whose run of positions contains it.
+        long long before = 0, N = 0;
+        for (int q = 0; q < G; ++q) { if (q < me) before += ends[q].n_bodies; N += ends[q].n_bodies; }
+        unsigned long long b = 0ull;
+        if (d >= 1 && d < G && N > 0) {
+            const long long t = min(N - 1, (long long)d * N / G);
+            if (t >= before && t < before + n) b = keys[t - before];
+        }
+        mine->new_bound[d] = b;
+    }
     if (d >= kLevels) return;
     Contrib c;
     c.m = c.mx = c.my = c.mz = 0.0; c.cnt = 0; c.base_after = -1;
@@ -226,13 +248,24 @@ __global__ __launch_bounds__(64) void k_let_contrib(const unsigned long long* __
 
 // ---- after the all-gather of the RoundB records
 // offsets[r] = first global index of rank r's slice, offsets[G] = total
-__global__ void k_let_offsets(const RoundB* __restrict__ rb, int G, int global_cap, int* __restrict__ offsets, int* __restrict__ out_flags) {
+__global__ void k_let_offsets(const RoundB* __restrict__ rb, int G, int global_cap, int* __restrict__ offsets, int* __restrict__ out_flags,
+                              unsigned long long* __restrict__ bounds) {
     if (threadIdx.x != 0) return;
     int run = 0, fl = 0;
     for (int q = 0; q < G; ++q) { offsets[q] = run; run += rb[q].n_nodes; fl |= rb[q].flags; }
     offsets[G] = run;
     if (run > global_cap) fl |= kFlagNodeCap;
     if (fl) atomicOr(out_flags, fl);
+    // the bounds the NEXT classification uses (this step's is done): whoever held quantile j reported its key
+    unsigned long long prev = 0ull;
+    bounds[0] = 0ull;
+    for (int j = 1; j < G; ++j) {
+        unsigned long long b = 0ull;
+        for (int q = 0; q < G; ++q) b = max(b, rb[q].new_bound[j]);
+        prev = max(prev, b);     // (monotone; an empty world leaves them all 0)
+        bounds[j] = prev;
+    }
+    bounds[G] = 1ull << 63;
 }
 // top[r][d] = the finished spanning cells (after the emit of my slice: it overwrites the ones that are mine)
 __global__ __launch_bounds__(64) void k_let_finalize(const RoundB* __restrict__ rb, const EndInfo* __restrict__ ends, int G, int me,
@@ -414,15 +447,18 @@ inline dim3 grid_for(int n, int bs) { return dim3((std::max(n, 1) + bs - 1) / bs
 }  // namespace
 
 void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float center[3], float width, const unsigned long long* bounds,
-                     int G, int me, Migrant* send, int* send_count, int mig_cap, int* flags, bool after_drift) {
-    if (n_upper <= 0) return;
-    hipLaunchKernelGGL(k_let_classify, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(),
-                       center[0], center[1], center[2], width, bounds, G, me, sh.keep, sh.escaped, send, send_count, mig_cap, flags, after_drift ? 1 : 0);
+                     int G, int me, unsigned char* dest_of, Migrant* send, int* send_count, int* send_off, int* cursor, bool after_drift) {
+    if (n_upper > 0)
+        hipLaunchKernelGGL(k_let_classify, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sh.own_count(), center[0], center[1],
+                           center[2], width, bounds, G, me, sh.keep, dest_of, sh.escaped, send_count, after_drift ? 1 : 0);
+    hipLaunchKernelGGL(k_let_mig_offsets, dim3(1), dim3(64), 0, s, send_count, G, send_off, cursor);
+    if (n_upper > 0)
+        hipLaunchKernelGGL(k_let_pack_migrants, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(),
+                           dest_of, send_off, cursor, send);
 }
-void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, const int* recv_count, int G, int mig_cap, int* flags,
-                   int* new_count, int* send_count) {
-    hipLaunchKernelGGL(k_let_append, grid_for(G * mig_cap, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(),
-                       sh.seg_cap, recv, recv_count, G, mig_cap, flags, new_count);
+void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, int n_in, int G, int* flags, int* new_count, int* send_count) {
+    hipLaunchKernelGGL(k_let_append, grid_for(n_in, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(), sh.seg_cap,
+                       recv, n_in, flags, new_count);
     hipLaunchKernelGGL(k_let_commit_count, dim3(1), dim3(64), 0, s, sh.own_count(), new_count, send_count, G, flags + 2);
 }
 void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
@@ -439,8 +475,8 @@ void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const 
     hipLaunchKernelGGL(k_let_contrib, dim3(G), dim3(64), 0, s, w.keys, w.delta, w.base, static_cast<const Sum4*>(w.incl), sh.own_count(), info,
                        ends, edge, G, me, mine);
 }
-void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags) {
-    hipLaunchKernelGGL(k_let_offsets, dim3(1), dim3(64), 0, s, rb, G, global_cap, offsets, out_flags);
+void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds) {
+    hipLaunchKernelGGL(k_let_offsets, dim3(1), dim3(64), 0, s, rb, G, global_cap, offsets, out_flags, bounds);
 }
 void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
                      const int* offsets, int* top_index) {

@@ -28,12 +28,19 @@ namespace let {
 
 struct State {
     int G = 1, me = 0;
-    int mig_cap = 4096;
     bool prune = true;
+    bool rebalance = true;        // redraw the ownership bounds every step (NBODY_LET_REBALANCE=0: keep the upload's)
+    unsigned long long* d_bounds_scratch = nullptr;   // [G + 1] where the redrawn bounds go when they are not used
     std::vector<unsigned long long> h_bounds;   // [G + 1]
     unsigned long long* d_bounds = nullptr;
-    Migrant *d_send_mig = nullptr, *d_recv_mig = nullptr;   // [G][mig_cap]
-    int *d_send_count = nullptr, *d_recv_count = nullptr;   // [G]
+    Migrant* d_send_mig = nullptr;   // [seg_cap] this step's emigrants, contiguous per destination
+    Migrant* d_recv_mig = nullptr;   // [mig_recv_cap] this step's immigrants
+    size_t mig_recv_cap = 0;
+    int mig_in = 0;                  // immigrants of this pass (host: the counts travel first)
+    uint64_t migrated_seen = 0;      // bodies_migrated at the last bookkeeping
+    unsigned char* d_dest_of = nullptr;   // [seg_cap] destination rank of every own body, 255: stays / left the box
+    int *d_send_count = nullptr, *d_send_off = nullptr, *d_mig_cursor = nullptr;   // [G], [G + 1], [G]
+    int* d_mig_matrix = nullptr;     // [G][G] row r = rank r's send counts (all-gathered)
     int* d_new_count = nullptr;
     int* d_flags = nullptr;       // [4] sticky flags (also the walk's poison word), step counter, bodies sent away so far
     int* d_box_ord = nullptr;     // [(kBoxes + 1) * 6]
@@ -145,12 +152,33 @@ int ensure_node_buffers(NbodyHandle* h, State& s) {
     if (s.ws_cap < size_t(sh.seg_cap)) {
         if (s.d_ws) (void)hipFree(s.d_ws);
         if (s.d_order) (void)hipFree(s.d_order);
-        s.d_ws = nullptr; s.d_order = nullptr;
+        if (s.d_send_mig) (void)hipFree(s.d_send_mig);
+        if (s.d_dest_of) (void)hipFree(s.d_dest_of);
+        s.d_ws = nullptr; s.d_order = nullptr; s.d_send_mig = nullptr; s.d_dest_of = nullptr;
+        {
+            int rc;
+            if ((rc = dev_alloc(h, &s.d_send_mig, size_t(sh.seg_cap)))) return rc;
+            if ((rc = dev_alloc(h, &s.d_dest_of, size_t(sh.seg_cap)))) return rc;
+        }
         HIP_TRY(h, hipMalloc(&s.d_ws, tree_build_workspace_bytes(size_t(sh.seg_cap))));
         int rc;
         if ((rc = dev_alloc(h, &s.d_order, size_t(sh.seg_cap)))) return rc;
         s.ws_cap = size_t(sh.seg_cap);
     }
+    return NBODY_OK;
+}
+
+// room for `need` immigrants; the first `keep` records of the old buffer survive a reallocation
+int ensure_mig_recv(NbodyHandle* h, State& s, size_t need, size_t keep) {
+    if (need <= s.mig_recv_cap) return NBODY_OK;
+    const size_t cap = need + need / 2 + 1024;
+    Migrant* fresh = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(Migrant)));
+    if (keep > 0 && s.d_recv_mig) HIP_TRY(h, hipMemcpyAsync(fresh, s.d_recv_mig, keep * sizeof(Migrant), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (s.d_recv_mig) (void)hipFree(s.d_recv_mig);
+    s.d_recv_mig = fresh;
+    s.mig_recv_cap = cap;
     return NBODY_OK;
 }
 
@@ -164,8 +192,9 @@ int phase0(NbodyHandle* h, State& s, float dt, bool drift) {
         if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
         launch_drift_half(h->stream, sh, int(h->n_local), dt, h->bnd);   // integrate_pre_force
     }
-    launch_classify(h->stream, sh, int(h->n_local), h->center, h->width, s.d_bounds, s.G, s.me, s.d_send_mig, s.d_send_count, s.mig_cap,
-                    s.d_flags, drift);
+    launch_classify(h->stream, sh, int(h->n_local), h->center, h->width, s.d_bounds, s.G, s.me, s.d_dest_of, s.d_send_mig, s.d_send_count,
+                    s.d_send_off, s.d_mig_cursor, drift);
+    s.mig_in = 0;
     launch_compact(h->stream, sh, int(h->n_local));                      // retain, and the emigrants leave
     h->count_dirty = true;
     HIP_TRY(h, hipGetLastError());
@@ -175,9 +204,9 @@ int phase0(NbodyHandle* h, State& s, float dt, bool drift) {
 int phase1(NbodyHandle* h, State& s) {
     Shard& sh = h->sh;
     PhaseTimer timer(h, s, 1);
-    launch_append(h->stream, sh, s.d_recv_mig, s.d_recv_count, s.G, s.mig_cap, s.d_flags, s.d_new_count, s.d_send_count);
-    // the host's bound of the own count: everything that could have arrived
-    h->n_local = std::min<size_t>(size_t(sh.seg_cap), h->n_local + size_t(s.G) * size_t(s.mig_cap));
+    launch_append(h->stream, sh, s.d_recv_mig, s.mig_in, s.G, s.d_flags, s.d_new_count, s.d_send_count);
+    // the host's bound of the own count: what was there before the retain + what arrived
+    h->n_local = std::min<size_t>(size_t(sh.seg_cap), h->n_local + size_t(s.mig_in));
     if (tree_sort_keys(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->center, h->width, s.d_ws, s.ws_cap, s.d_tree_info, &s.work) != 0)
         return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
     launch_ends(h->stream, sh, int(h->n_local), s.work.keys, s.work.ids, s.d_box_ord, s.d_ends + s.me);
@@ -201,7 +230,7 @@ int phase3(NbodyHandle* h, State& s) {
     Shard& sh = h->sh;
     PhaseTimer timer(h, s, 3);
     HIP_TRY(h, hipMemsetAsync(s.d_let_count, 0, sizeof(int) * s.G, h->stream));
-    launch_offsets(h->stream, s.d_rb, s.G, s.global_cap, s.d_offsets, s.d_flags);
+    launch_offsets(h->stream, s.d_rb, s.G, s.global_cap, s.d_offsets, s.d_flags, s.rebalance ? s.d_bounds : s.d_bounds_scratch);
     // my slice, straight to its place in the global-index array
     if (tree_emit_nodes(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->width, s.d_ws, s.ws_cap, s.d_global, s.global_cap, s.local_cap,
                         s.d_order, s.d_tree_info, 0, s.d_edge, s.d_offsets + s.me, s.d_parent, s.d_depth) != 0)
@@ -254,14 +283,15 @@ int create(NbodyHandle* h) {
     s.G = h->cfg.world_size;
     s.me = h->cfg.rank;
     if (s.G > kMaxRanks) return fail(h, NBODY_ERR_INVALID, "NBODY_SHARD_SPATIAL supports up to 16 ranks");
-    if (const char* v = std::getenv("NBODY_LET_MIG_CAP")) s.mig_cap = std::max(16, std::atoi(v));
     s.recv_n.assign(s.G, 0);
     int rc;
     if ((rc = dev_alloc(h, &s.d_bounds, size_t(s.G) + 1))) return rc;
-    if ((rc = dev_alloc(h, &s.d_send_mig, size_t(s.G) * s.mig_cap))) return rc;
-    if ((rc = dev_alloc(h, &s.d_recv_mig, size_t(s.G) * s.mig_cap))) return rc;
+    if ((rc = dev_alloc(h, &s.d_bounds_scratch, size_t(s.G) + 1))) return rc;
+    if (const char* v = std::getenv("NBODY_LET_REBALANCE")) s.rebalance = std::atoi(v) != 0;
     if ((rc = dev_alloc(h, &s.d_send_count, size_t(s.G)))) return rc;
-    if ((rc = dev_alloc(h, &s.d_recv_count, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_send_off, size_t(s.G) + 1))) return rc;
+    if ((rc = dev_alloc(h, &s.d_mig_cursor, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_mig_matrix, size_t(s.G) * s.G))) return rc;
     if ((rc = dev_alloc(h, &s.d_new_count, 1))) return rc;
     if ((rc = dev_alloc(h, &s.d_flags, 4))) return rc;
     if ((rc = dev_alloc(h, &s.d_box_ord, (kBoxes + 1) * 6))) return rc;
@@ -291,7 +321,7 @@ int create(NbodyHandle* h) {
 void destroy(NbodyHandle* h) {
     State* s = h->let;
     if (!s) return;
-    void* dev[] = {s->d_bounds, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_recv_count, s->d_new_count, s->d_flags, s->d_box_ord,
+    void* dev[] = {s->d_bounds, s->d_bounds_scratch, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_send_off, s->d_mig_cursor, s->d_mig_matrix, s->d_dest_of, s->d_new_count, s->d_flags, s->d_box_ord,
                    s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_global, s->d_order, s->d_tree_info,
                    s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_send,
                    s->d_let_recv, s->d_let_matrix, h->sh.ids};
@@ -348,7 +378,6 @@ int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     if (m) HIP_TRY(h, hipMemcpyAsync(sh.ids, own.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(sh.escaped, 0, sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d_send_count, 0, sizeof(int) * s.G, h->stream));
-    HIP_TRY(h, hipMemsetAsync(s.d_recv_count, 0, sizeof(int) * s.G, h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d_flags, 0, 4 * sizeof(int), h->stream));
     h->n_local = m;
     h->seg_count_host[0] = int(m);
@@ -381,8 +410,14 @@ int check_flags(NbodyHandle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int f = s.h_pin[0];
     if (!f) return NBODY_OK;
-    if (f & (kFlagDeep)) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 42 levels (coincident?)");
-    if (f & kFlagMigOverflow) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: more bodies migrate to one rank in a step than NBODY_LET_MIG_CAP");
+    std::string who;   // which ranks' builds raised something (their RoundB records are here)
+    {
+        std::vector<RoundB> rb(size_t(s.G));
+        if (hipMemcpy(rb.data(), s.d_rb, sizeof(RoundB) * s.G, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int q = 0; q < s.G; ++q) if (rb[q].flags) who += " rank " + std::to_string(q) + ": build flags " + std::to_string(rb[q].flags) + ";";
+        who += " flag word " + std::to_string(f);
+    }
+    if (f & (kFlagDeep)) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 42 levels (coincident?);" + who);
     if (f & kFlagCapacity) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: a rank's capacity is exhausted by immigrants");
     if (f & (kFlagNodeCap | kFlagNodeCapLocal)) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: node array too small");
     return fail(h, NBODY_ERR_INVALID, "spatial shards: the device raised flag " + std::to_string(f));
@@ -426,7 +461,10 @@ static int account(NbodyHandle* h, State& s) {
     h->seg_count_host[0] = int(h->n_local);
     h->count_dirty = false;
     const uint64_t partners = uint64_t(std::max(0, s.G - 1));
-    s.st.bytes_sent += sent * sizeof(LetRecord) + partners * (uint64_t(s.mig_cap) * sizeof(Migrant) + sizeof(EndInfo) + sizeof(RoundB));
+    const uint64_t migrated_now = uint64_t(std::max(0, s.h_pin[44]));
+    s.st.bytes_sent += sent * sizeof(LetRecord) + (migrated_now - std::min(migrated_now, s.migrated_seen)) * sizeof(Migrant) +
+                       partners * (2 * uint64_t(s.G) * sizeof(int) + sizeof(EndInfo) + sizeof(RoundB));
+    s.migrated_seen = migrated_now;
     s.st.bytes_allgather_equivalent += partners * uint64_t(std::max(0, s.h_pin[42])) * 16ull;
     uint64_t rec = 0;
     for (int n : s.recv_n) rec += uint64_t(n);
@@ -446,16 +484,25 @@ static int pass(NbodyHandle* h, float dt, bool is_step) {
     if (s.G > 1 && !h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
     int rc = phase0(h, s, dt, is_step);
     if (rc) return rc;
-    if (s.G > 1) {   // exchange 0: slot r of my send buffer -> rank r; its slot for me <- rank r
+    if (s.G > 1) {   // exchange 0: the counts first (row r = what rank r sends to everybody), then the migrants themselves
+        NCCL_TRY(h, ncclAllGather(s.d_send_count, s.d_mig_matrix, size_t(s.G), ncclInt32, h->comm, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_mig_matrix, sizeof(int) * s.G * s.G, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        size_t total_in = 0;
+        for (int r = 0; r < s.G; ++r) if (r != s.me) total_in += size_t(std::max(0, s.h_pin[r * s.G + s.me]));
+        rc = ensure_mig_recv(h, s, total_in, 0);
+        if (rc) return rc;
         NCCL_TRY(h, ncclGroupStart());
+        size_t out_at = 0, in_at = 0;
         for (int r = 0; r < s.G; ++r) {
-            if (r == s.me) continue;
-            NCCL_TRY(h, ncclSend(s.d_send_mig + size_t(r) * s.mig_cap, size_t(s.mig_cap) * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
-            NCCL_TRY(h, ncclRecv(s.d_recv_mig + size_t(r) * s.mig_cap, size_t(s.mig_cap) * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
-            NCCL_TRY(h, ncclSend(s.d_send_count + r, 1, ncclInt32, r, h->comm, h->stream));
-            NCCL_TRY(h, ncclRecv(s.d_recv_count + r, 1, ncclInt32, r, h->comm, h->stream));
+            const size_t out = size_t(std::max(0, s.h_pin[s.me * s.G + r]));   // (0 for r == me: a body that stays is not counted)
+            const size_t in = r == s.me ? 0 : size_t(std::max(0, s.h_pin[r * s.G + s.me]));
+            if (r != s.me && out > 0) NCCL_TRY(h, ncclSend(s.d_send_mig + out_at, out * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
+            if (in > 0) NCCL_TRY(h, ncclRecv(s.d_recv_mig + in_at, in * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
+            out_at += out; in_at += in;
         }
         NCCL_TRY(h, ncclGroupEnd());
+        s.mig_in = int(total_in);
     }
     rc = phase1(h, s);
     if (rc) return rc;
@@ -528,11 +575,19 @@ int debug_exchange(NbodyHandle* h, NbodyHandle* peer, int which) {
     const int me = s.me, pr = p.me;
     HIP_TRY(h, hipStreamSynchronize(peer->stream));
     switch (which) {
-        case 0:   // migrants: the peer's slot for me
-            HIP_TRY(h, hipMemcpyAsync(s.d_recv_mig + size_t(pr) * s.mig_cap, p.d_send_mig + size_t(me) * p.mig_cap, size_t(s.mig_cap) * sizeof(Migrant),
-                                      hipMemcpyDeviceToDevice, h->stream));
-            HIP_TRY(h, hipMemcpyAsync(s.d_recv_count + pr, p.d_send_count + me, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        case 0: { // migrants: the peer's run for me, behind what has arrived already
+            int cnt = 0, off = 0;
+            HIP_TRY(h, hipMemcpy(&cnt, p.d_send_count + me, sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipMemcpy(&off, p.d_send_off + me, sizeof(int), hipMemcpyDeviceToHost));
+            if (cnt > 0) {
+                int rc = ensure_mig_recv(h, s, size_t(s.mig_in) + size_t(cnt), size_t(s.mig_in));
+                if (rc) return rc;
+                HIP_TRY(h, hipMemcpyAsync(s.d_recv_mig + s.mig_in, p.d_send_mig + off, size_t(cnt) * sizeof(Migrant), hipMemcpyDeviceToDevice,
+                                          h->stream));
+                s.mig_in += cnt;
+            }
             break;
+        }
         case 1:
             HIP_TRY(h, hipMemcpyAsync(s.d_ends + pr, p.d_ends + pr, sizeof(EndInfo), hipMemcpyDeviceToDevice, h->stream));
             break;
@@ -569,5 +624,11 @@ int debug_exchange(NbodyHandle* h, NbodyHandle* peer, int which) {
 extern "C" int nbody_debug_let_set_prune(NbodyHandle* h, int prune) {
     if (!h || !h->let) return NBODY_ERR_INVALID;
     h->let->prune = prune != 0;
+    return NBODY_OK;
+}
+
+extern "C" int nbody_debug_let_bounds(NbodyHandle* h, unsigned long long* out) {
+    if (!h || !h->let || !out) return NBODY_ERR_INVALID;
+    if (hipMemcpy(out, h->let->d_bounds, (size_t(h->let->G) + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return NBODY_ERR_HIP;
     return NBODY_OK;
 }

@@ -79,7 +79,9 @@ def test_upload_deals_key_ranges_and_download_ids_restore_the_vector(gpu, G):
 @pytest.mark.parametrize("G", [2, 4])
 def test_migration_keeps_ownership_by_key_range(gpu, G):
     """g = 0: straight lines, exactly reproducible in numpy float32.  Bodies cross the key-range bounds and the box walls;
-    after every step each rank holds exactly the bodies whose key lies in its range, nothing is lost or duplicated."""
+    after every step each rank holds exactly the bodies whose key lies in its range, nothing is lost or duplicated.  The
+    bounds are redrawn every step at the G-quantiles of the world's keys (they apply from the next step on), so the
+    ranks stay balanced while the box empties."""
     nb = gpu
     n = 4000
     rng = np.random.default_rng(5)
@@ -91,7 +93,8 @@ def test_migration_keeps_ownership_by_key_range(gpu, G):
     dt = np.float32(0.05)
     sims = make_world(nb, ics, G, box, nb.Settings(0.0, 0.0, float(dt), 0.25))
     key0 = host_keys(nb, ics, box)
-    bounds = [np.sort(key0)[min(n - 1, r * n // G)] for r in range(1, G)]
+    bounds = sims[0].let_bounds()
+    assert [int(b) for b in bounds[1:G]] == [int(np.sort(key0)[min(n - 1, r * n // G)]) for r in range(1, G)]   # the upload's quantiles
     x = ics["position"].copy()
     alive = np.arange(n)
     half = (ics["velocity"] * np.float32(0.5)) * dt
@@ -109,10 +112,14 @@ def test_migration_keeps_ownership_by_key_range(gpu, G):
         tmp = np.zeros(len(tree_pos), nb.PARTICLE_DTYPE)
         tmp["position"] = tree_pos
         k = host_keys(nb, tmp, box)
-        owner = np.searchsorted(np.array(bounds, np.uint64), k, side="right")
+        owner = np.searchsorted(bounds[1:G], k, side="right")   # this step classified with the bounds drawn in the step before
         for r, s in enumerate(sims):
             ids = s.download_ids()
             assert set(ids.tolist()) == set(alive[owner == r].tolist()), (step, r)
+        bounds = sims[0].let_bounds()
+        assert all(np.array_equal(s.let_bounds(), bounds) for s in sims)
+        ks = np.sort(k)                                       # ... and the new ones are this step's quantiles
+        assert [int(b) for b in bounds[1:G]] == [int(ks[min(len(ks) - 1, r * len(ks) // G)]) for r in range(1, G)], step
     assert len(alive) < 0.9 * n
     close(sims)
 
@@ -284,3 +291,17 @@ def test_spatial_single_rank_with_a_communicator(gpu):
         ref = one.get_points()
     assert np.array_equal(ids, np.arange(3000))
     assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-6
+
+
+def test_randomised_worlds_against_the_single_gpu_run():
+    """tools/let_stress.py: 150 random worlds (1-8 ranks, 1-30 000 bodies, spheres / clumps / lines / planes / one octant /
+    near pairs, four box sizes, four thetas, both leaf rules, up to 6 steps with escapes and migration), each compared
+    step by step with the single-GPU device-tree run until their trajectories part by rounding."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "let_stress.py"), "--cases", "150", "--seed", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all OK" in r.stdout

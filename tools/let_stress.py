@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Randomised stress of the spatial-shard Barnes-Hut path against the single-GPU device-tree run (one-GPU emulation of
+the ranks): random world sizes, body counts, boxes, theta, clustered and degenerate initial conditions, several steps
+with escapes and migration.  Prints one line per case; exits non-zero at the first mismatch.
+
+    python tools/let_stress.py [--cases 200] [--seed 1] [--max-n 30000]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
+
+
+def make_ics(nb, rng, n, kind):
+    ics = nb.plummer(n, seed=int(rng.integers(1, 1 << 30)))
+    if kind == "two_clumps":
+        half = n // 2
+        ics["position"][:half] = ics["position"][:half] * np.float32(0.2) + np.float32([1.5, 0.3, -0.2])
+        ics["position"][half:] = ics["position"][half:] * np.float32(0.3) - np.float32([1.0, 1.0, 0.5])
+    elif kind == "line":
+        ics["position"][:, 1:] *= np.float32(1e-3)
+    elif kind == "plane":
+        ics["position"][:, 2] *= np.float32(1e-4)
+    elif kind == "corner":
+        ics["position"] = np.abs(ics["position"]) * np.float32(0.3) + np.float32(0.01)     # one octant only: most ranks deep in one cell
+    elif kind == "near_pairs":
+        k = max(1, n // 50)
+        src = rng.integers(0, n, k)
+        dst = rng.integers(0, n, k)
+        ok = src != dst
+        ics["position"][dst[ok]] = ics["position"][src[ok]] + rng.integers(1, 9, (int(ok.sum()), 3)).astype(np.float32) * np.float32(1.2e-7)
+    return ics
+
+
+def step_by_step(nb, ics, box, st, G, leaf, steps):
+    n = len(ics)
+    one = nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE, leaf_mode=leaf)
+    one.settings = st
+    one.init()
+    sims = [nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, rank=r, world_size=G, capacity=n, shard_mode=nb.SHARD_SPATIAL,
+                          leaf_mode=leaf) for r in range(G)]
+    for s in sims:
+        s.settings = st
+        s.init()
+    nb.spatial_step(sims, forces_only=True)
+    one.update_forces()
+    print("bounds", [hex(int(b)) for b in sims[0].let_bounds()], "owned", [len(s) for s in sims], flush=True)
+    for k in range(steps):
+        one.step()
+        try:
+            nb.spatial_step(sims)
+        except nb.NbodyError as e:
+            print(f"step {k}: {e}; bounds", [hex(int(b)) for b in sims[0].let_bounds()], flush=True)
+            raise
+        print("bounds", [hex(int(b)) for b in sims[0].let_bounds()], "owned", [len(s) for s in sims], flush=True)
+        ref = one.get_points()
+        rec, idx = nb.spatial_gather(sims, n)
+        scale = float(np.abs(ref["acceleration"]).max()) or 1.0
+        err = np.abs(rec["acceleration"].astype(np.float64) - ref["acceleration"]).max(axis=1) / scale
+        perr = np.abs(rec["position"].astype(np.float64) - ref["position"]).max(axis=1)
+        verr = np.abs(rec["velocity"].astype(np.float64) - ref["velocity"]).max(axis=1)
+        s1 = one.stats()
+        st_ = [s.stats() for s in sims]
+        bad = np.flatnonzero(err > 1e-5)[:6]
+        for b in bad:
+            d = rec["acceleration"][b].astype(np.float64) - ref["acceleration"][b]
+            others = np.linalg.norm(ref["position"].astype(np.float64) - ref["position"][b], axis=1)
+            others[b] = np.inf
+            nn = int(others.argmin())
+            sep = ref["position"][nn].astype(np.float64) - ref["position"][b]
+            r2 = float(sep @ sep)
+            pair = float(ref["mass"][nn]) * sep / (r2 + st.g_soft ** 2) ** 1.5
+            print(f"   body {b}: acc diff {d} nearest {nn} at {np.sqrt(r2):.3e} pair force {pair} pos diff {rec['position'][b].astype(np.float64) - ref['position'][b]}")
+        print(f"step {k}: survivors {len(ref)}/{len(rec)} acc err max {err.max():.2e} (>1e-5: {(err > 1e-5).sum()}, >1e-6: {(err > 1e-6).sum()}) "
+              f"pos err {perr.max():.2e} vel err {verr.max():.2e} |a|max {scale:.3e} visits {s1.node_visits} / {sum(s.node_visits for s in st_)} "
+              f"accepted {s1.interactions} / {sum(s.interactions for s in st_)}", flush=True)
+    one.close()
+    for s in sims:
+        s.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-n", type=int, default=30000)
+    ap.add_argument("--only", type=int, default=-1, help="run this case alone (the random stream is consumed as in a full run) and compare step by step")
+    a = ap.parse_args()
+    nb = graft.load_package()
+    rng = np.random.default_rng(a.seed)
+    kinds = ["plummer", "two_clumps", "line", "plane", "corner", "near_pairs"]
+    t_start = time.time()
+    for case in range(a.cases):
+        G = int(rng.integers(1, 9))
+        n = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 2000)), int(rng.integers(2000, a.max_n))]))
+        kind = kinds[int(rng.integers(0, len(kinds)))]
+        width = float(rng.choice([64.0, 8.0, 3.0, 1.7]))
+        theta2 = float(rng.choice([0.25, 0.49, 1.0, 0.04]))
+        steps = int(rng.integers(1, 7))
+        leaf = nb.LEAF_DIRECT if rng.random() < 0.3 else nb.LEAF_REFERENCE
+        dt = float(rng.choice([1e-3, 5e-3, 2e-2]))
+        box = ((0.0, 0.0, 0.0), width)
+        st = nb.Settings(1.0, 0.02, dt, theta2)
+        ics = make_ics(nb, rng, n, kind)
+        # the reference's callers hand over bodies inside the root box (two bodies beyond the same corner never separate:
+        # its build_tree would recurse for ever); bodies may LEAVE the box during the run
+        ics = ics[(np.abs(ics["position"]) <= np.float32(width / 2)).all(axis=1)]
+        if len(ics) == 0:
+            continue
+        n = len(ics)
+        if a.only >= 0 and case != a.only:
+            continue
+        tag = f"case {case}: G={G} n={n} {kind} width={width} theta2={theta2} steps={steps} leaf={'direct' if leaf == nb.LEAF_DIRECT else 'ref'} dt={dt}"
+        if a.only >= 0:
+            step_by_step(nb, ics, box, st, G, leaf, steps)
+            return
+        try:
+            one = nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE, leaf_mode=leaf)
+            one.settings = st
+            one.init()
+            one.update_forces()
+            one.sync()
+            one.get_points()   # (an unsynchronised run reports a refused build at the next read-back)
+        except nb.NbodyError as e:
+            print(tag, "-> single-GPU run refused:", e, flush=True)
+            continue
+        sims = [nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, rank=r, world_size=G, capacity=max(1, n), shard_mode=nb.SHARD_SPATIAL,
+                              leaf_mode=leaf) for r in range(G)]
+        ok, flipped, worst, note, pos_equal = True, False, 0.0, "", True
+        try:
+            for s in sims:
+                s.settings = st
+                s.init()
+            nb.spatial_step(sims, forces_only=True)
+            for k in range(steps):
+                one.step()
+                nb.spatial_step(sims)
+                ref = one.get_points()
+                s1 = one.stats()
+                rec, idx = nb.spatial_gather(sims, n)
+                stats = [s.stats() for s in sims]
+                if len(rec) != len(ref) or not all(s.tree_nodes == s1.tree_nodes for s in stats):
+                    if flipped or not pos_equal:   # trajectories that parted (even by an ulp) may lose different bodies and build different trees
+                        note = " (trajectories parted: different trees from here on)"
+                        break
+                    ok, note = False, f" step {k}: survivors {len(rec)}/{len(ref)} nodes {[s.tree_nodes for s in stats]}/{s1.tree_nodes}"
+                    break
+                if len(ref) == 0:
+                    break
+                scale = float(np.abs(ref["acceleration"]).max()) or 1.0
+                err = np.abs(rec["acceleration"].astype(np.float64) - ref["acceleration"]).max(axis=1) / scale
+                same_counts = sum(s.interactions for s in stats) == s1.interactions and sum(s.node_visits for s in stats) == s1.node_visits
+                worst = max(worst, float(err.max()))
+                far = int((err > 1e-5).sum())
+                pos_equal = pos_equal and bool(np.array_equal(rec["position"], ref["position"]))
+                if not flipped:
+                    # before any opening test has fallen the other way the two runs differ by rounding only; a flip (a
+                    # centre of mass that differs in its last bit) moves ONE body by that node's truncation error -- the
+                    # totals can even stay equal when two flips cancel -- so: a handful of bodies, bounded
+                    if far > max(2, len(ref) // 2000) or err.max() > 5e-2 or not np.array_equal(rec["mass"], ref["mass"]):
+                        ok, note = False, f" step {k}: acc err {err.max():.2e}, {far} bodies beyond 1e-5 (counts {'equal' if same_counts else 'differ'})"
+                        break
+                    flipped = far > 0 or not same_counts
+                elif err.max() > 0.5:   # after a flip a dense system amplifies the difference step by step: only sanity from here on
+                    ok, note = False, f" step {k}: acc err {err.max():.2e} after a flip"
+                    break
+        except nb.NbodyError as e:
+            ok, note = False, f" FAILED with {e}"
+        finally:
+            one.close()
+            for s in sims:
+                s.close()
+        print(tag, f"-> worst acc err {worst:.2e}{' (flip)' if flipped else ''}{note}", "OK" if ok else "MISMATCH", flush=True)
+        if not ok:
+            sys.exit(1)
+    print(f"{a.cases} cases in {time.time() - t_start:.0f} s: all OK")
+
+
+if __name__ == "__main__":
+    main()
