@@ -236,6 +236,8 @@ int nbody_debug_step_end(NbodyHandle* h, float dt);
  * 1 end info, 2 spanning-cell tables, 3 nodes).  prune = 0 in nbody_debug_let_set_prune exports every private node. */
 int nbody_debug_let_phase(NbodyHandle* h, int phase, float dt);
 int nbody_debug_let_exchange(NbodyHandle* h, NbodyHandle* peer, int which);
+/* by_work = 1 (default): the redrawn bounds give every rank the same share of the last walk's node visits; 0: of the bodies */
+int nbody_debug_let_set_balance(NbodyHandle* h, int by_work);
 /* the key-range bounds the next classification will use ([world_size + 1]; redrawn every step at the world's quantiles) */
 int nbody_debug_let_bounds(NbodyHandle* h, unsigned long long* out);
 int nbody_debug_let_set_prune(NbodyHandle* h, int prune);

@@ -68,7 +68,7 @@ DECLARED_SYMBOLS = [
     "nbody_set_settings_f64", "nbody_get_settings_f64", "nbody_set_bounds_f64", "nbody_step_by_f64", "nbody_elapsed_f64",
     "nbody_tree_export_f64", "nbody_ic_plummer_f64", "nbody_ic_disc_f64",
     "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
-    "nbody_debug_let_bounds",
+    "nbody_debug_let_bounds", "nbody_debug_let_set_balance",
 ]
 
 
@@ -159,6 +159,7 @@ _sig("nbody_debug_let_phase", _i, _H, _i, _f)
 _sig("nbody_debug_let_exchange", _i, _H, _H, _i)
 _sig("nbody_debug_let_set_prune", _i, _H, _i)
 _sig("nbody_debug_let_bounds", _i, _H, C.c_void_p)
+_sig("nbody_debug_let_set_balance", _i, _H, _i)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
 
@@ -418,6 +419,10 @@ class Simulation:
         out = np.zeros(self.world_size + 1, np.uint64)
         self._check(lib.nbody_debug_let_bounds(self._h, out.ctypes.data))
         return out
+
+    def set_balance(self, by_work: bool):
+        """NBODY_SHARD_SPATIAL: redraw the bounds at the quantiles of the last walk's visit counts (default) or of the body count."""
+        self._check(lib.nbody_debug_let_set_balance(self._h, int(bool(by_work))))
 
     def set_prune(self, on: bool):
         self._check(lib.nbody_debug_let_set_prune(self._h, int(bool(on))))

@@ -126,6 +126,7 @@ struct TreeDev {
     // to walk from the device
     const int* poison = nullptr;
     const int* n_order_dev = nullptr;
+    int store_work = 0;              // the plain walk leaves every body's visit count in acc.w (spatial shards)
     // fast math: the cooperative block walk (k_bh_walk_block) reads this level-order copy of `nodes`, built per step
     float4* bfs = nullptr;           // [n_nodes] records {com, mass | w^2, pre-order index, pre-order skip, first child | last flag}
     void* bfs_ws = nullptr;          // workspace of build_bfs_layout
@@ -138,6 +139,7 @@ struct TreeDevWork {  // arrays of the last build (inside its workspace)
     const int* base = nullptr;                  // first node of every sorted body
     const int* ids = nullptr;                   // sorted position -> body
     const unsigned long long* keys2 = nullptr;  // levels 21..41, defined inside groups of equal keys only
+    const int* wpre = nullptr;                  // exclusive prefix sums of the bodies' weights over the sorted order (tree_scan_sorted with weights)
     const void* incl = nullptr;                 // inclusive f64 prefix sums {m, m x, m y, m z} over the sorted bodies (4 doubles each)
 };
 struct TreeCat {  // sharded runs: side buffer of the device build
@@ -167,7 +169,9 @@ int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n
 // the two halves of tree_emit_sorted, for the spatial-shard build (the nodes are emitted after an exchange, at an offset
 // in the global-index array, with each node's parent and depth)
 int tree_scan_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info,
-                     const int* edge);
+                     const int* edge, const float4* weight_src = nullptr /* acc: .w = last walk's visit count */);
+// the weight a body's visit count stands for in the balance of spatial shards (>= 1; scaled so that 2^31 is far away)
+__host__ __device__ inline int body_weight(float visits) { const int v = int(visits) >> 4; return v < 1 ? 1 : v; }
 int tree_emit_nodes(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
                     float4* nodes, int node_cap, int slice_cap, int* order, int* out_info, int want_hot, const int* edge,
                     const int* node_offset, int* parent, unsigned char* depth);

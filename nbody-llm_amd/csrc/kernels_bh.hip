@@ -45,6 +45,7 @@ struct WalkSplit {
     int diag_first;          // k_bh_walk: segments of a body group in order of distance from its own place in the tree
     const int* poison;       // unsynchronised steps: != 0 -> do nothing (Shard::poison); may be null
     const int* n_order_dev;  // unsynchronised steps: the live number of bodies to walk (the host's is an upper bound); may be null
+    int store_work;          // k_bh_walk, one segment: the body's visit count goes to acc.w (spatial shards balance by it)
 };
 constexpr int kMaxAnc = 192;
 
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
                 i = i + 1;
             }
         }
-        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] =
+            make_float4(ax, ay, az, split.store_work ? float(n_vis) : 0.f);  // :260
     }
     if (DBG) {
         unsigned int it = n_vis;
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_pair(const NodeDev* __re
         i = pair_from_even(next);
     }
     if (live && !half)
-        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] =
+            make_float4(ax, ay, az, split.store_work ? float(n_vis) : 0.f);  // :260
     if (half) { n_acc = 0; n_vis = 0; }
     for (int off = 32; off > 0; off >>= 1) {
         n_acc += __shfl_down(n_acc, off);
@@ -784,7 +787,8 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk_lds(const NodeDev* __restrict
                 u = l_open;
             }
         }
-        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] =
+            make_float4(ax, ay, az, split.store_work ? float(n_vis) : 0.f);  // :260
     }
     for (int off = 32; off > 0; off >>= 1) {
         n_acc += __shfl_down(n_acc, off);
@@ -855,6 +859,7 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
     sp.diag_first = nbody_bh_walk_order;
     sp.poison = t.poison; sp.n_order_dev = t.n_order_dev;
+    sp.store_work = t.store_work;
     dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
     if (fast_math && nbody_bh_walk_variant == 3 && t.hot_cap > 0 && t.walk) {
         const int M = t.hot_cap;

@@ -22,6 +22,7 @@ constexpr int kBoxes = 1 << (3 * kBoxDigits);   // below the deepest cell that h
 struct EndInfo {                // what every rank tells the others after its sort (all-gathered)
     unsigned long long first_key, last_key;   // of its sorted bodies
     int n_bodies, pad;
+    long long weight;                         // sum of its bodies' weights (body_weight of the last walk's visit counts)
     float lo[3], hi[3];                       // bounding box of all its bodies (quick reject)
     float box_lo[kBoxes][3], box_hi[kBoxes][3];   // of its bodies in each child cell; lo > hi: none there
 };
@@ -48,10 +49,10 @@ void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float ce
                      int G, int me, unsigned char* dest_of, Migrant* send, int* send_count, int* send_off, int* cursor, bool after_drift);
 void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, int n_in, int G, int* flags, int* new_count, int* send_count);
 void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
-                 EndInfo* mine);
+                 unsigned long long* weight_sum, EndInfo* mine);
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge);
 void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
-                    RoundB* mine);
+                    RoundB* mine, bool balance_by_work);
 void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds);
 void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
                      const int* offsets, int* top_index);

@@ -139,10 +139,14 @@ __global__ void k_let_commit_count(int* __restrict__ count, const int* __restric
 
 // ---- what the other ranks need to know about this one before the second half of the build
 // box_ord[0..5] = the overall box, box_ord[6 + 6 b ..] = the box of child cell b, as order-preserving ints (min / max atomics)
-__global__ __launch_bounds__(256) void k_let_box(const float4* __restrict__ pos, const unsigned long long* __restrict__ keys,
-                                                 const int* __restrict__ ids, const int* __restrict__ count, int* __restrict__ box_ord) {
+__global__ __launch_bounds__(256) void k_let_box(const float4* __restrict__ pos, const float4* __restrict__ acc,
+                                                 const unsigned long long* __restrict__ keys, const int* __restrict__ ids,
+                                                 const int* __restrict__ count, int* __restrict__ box_ord,
+                                                 unsigned long long* __restrict__ weight_sum) {
     __shared__ int red[kBoxes + 1][6];
+    __shared__ int wsum_s;
     const int n = *count;
+    if (threadIdx.x == 0) wsum_s = 0;
     for (int t = threadIdx.x; t < (kBoxes + 1) * 6; t += 256) red[t / 6][t % 6] = (t % 6) < 3 ? 0x7fffffff : int(0x80000000);
     __syncthreads();
     const int j = blockIdx.x * 256 + threadIdx.x;   // sorted position
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256) void k_let_box(const float4* __restrict__ pos,
         const int c = min(common_levels(keys[0], keys[n - 1]), kLevels - kBoxDigits);   // the deepest cell holding all my bodies
         const int g = int((keys[j] >> (3 * (kLevels - kBoxDigits - c))) & (unsigned long long)(kBoxes - 1));
         const float4 p = pos[ids[j]];
+        atomicAdd(&wsum_s, body_weight(acc[ids[j]].w));   // what the body cost in the last walk (1 before the first)
         const int o[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
         for (int a = 0; a < 3; ++a) {
             atomicMin(&red[g][a], o[a]); atomicMax(&red[g][3 + a], o[a]);
@@ -163,11 +168,14 @@ __global__ __launch_bounds__(256) void k_let_box(const float4* __restrict__ pos,
         if (a < 3) { if (v != 0x7fffffff) atomicMin(dst, v); }
         else if (v != int(0x80000000)) atomicMax(dst, v);
     }
+    if (threadIdx.x == 0 && wsum_s > 0) atomicAdd(weight_sum, (unsigned long long)wsum_s);
 }
 __global__ void k_let_ends(const unsigned long long* __restrict__ sorted_keys, const int* __restrict__ count, int* __restrict__ box_ord,
-                           EndInfo* __restrict__ mine) {
+                           unsigned long long* __restrict__ weight_sum, EndInfo* __restrict__ mine) {
     const int n = *count;
     if (threadIdx.x == 0) {
+        mine->weight = n > 0 ? (long long)*weight_sum : 0ll;
+        *weight_sum = 0ull;   // for the next step
         mine->first_key = n > 0 ? sorted_keys[0] : 0ull;
         mine->last_key = n > 0 ? sorted_keys[n - 1] : 0ull;
         mine->n_bodies = n; mine->pad = 0;
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(64) void k_let_contrib(const unsigned long long* __
                                                     const int* __restrict__ base, const Sum4* __restrict__ incl,
                                                     const int* __restrict__ count, const int* __restrict__ info /* {n_nodes, flags} */,
                                                     const EndInfo* __restrict__ ends, const int* __restrict__ edge, int G, int me,
-                                                    RoundB* __restrict__ mine) {
+                                                    RoundB* __restrict__ mine, const int* __restrict__ wpre, int by_work) {
     const int r = blockIdx.x;      // the rank whose spanning cells are concerned
     const int d = threadIdx.x;     // depth
     const int n = *count;
@@ -206,12 +214,28 @@ __global__ __launch_bounds__(64) void k_let_contrib(const unsigned long long* __
     if (r == 0 && d < kMaxRanks) {
         // Next step's bounds.  The world's sorted order is the concatenation of the ranks' sorted orders, so its G-quantiles
         // are plain look-ups: quantile j sits at global position j N / G, on the rank whose run of positions contains it.
-        long long before = 0, N = 0;
-        for (int q = 0; q < G; ++q) { if (q < me) before += ends[q].n_bodies; N += ends[q].n_bodies; }
+        // By weight (the walk's visit counts of the last step): the same with the running sum of the weights in the place
+        // of the position -- the ranks then get equal WORK, not equal body counts.
+        long long before = 0, N = 0, mine_n = n;
+        for (int q = 0; q < G; ++q) {
+            const long long c = by_work ? ends[q].weight : (long long)ends[q].n_bodies;
+            if (q < me) before += c;
+            if (q == me) mine_n = c;
+            N += c;
+        }
         unsigned long long b = 0ull;
-        if (d >= 1 && d < G && N > 0) {
+        if (d >= 1 && d < G && N > 0 && n > 0) {
             const long long t = min(N - 1, (long long)d * N / G);
-            if (t >= before && t < before + n) b = keys[t - before];
+            if (t >= before && t < before + mine_n) {
+                int k = int(t - before);
+                if (by_work) {          // the body whose run of the weight line contains t: last k with wpre[k] <= t - before
+                    const int tw = int(t - before);
+                    int a = 0, e = n - 1;
+                    while (a < e) { const int mid = (a + e + 1) >> 1; if (wpre[mid] <= tw) a = mid; else e = mid - 1; }
+                    k = a;
+                }
+                b = keys[min(k, n - 1)];
+            }
         }
         mine->new_bound[d] = b;
     }
@@ -462,18 +486,19 @@ void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, int n_in
     hipLaunchKernelGGL(k_let_commit_count, dim3(1), dim3(64), 0, s, sh.own_count(), new_count, send_count, G, flags + 2);
 }
 void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
-                 EndInfo* mine) {
+                 unsigned long long* weight_sum, EndInfo* mine) {
     if (n_upper > 0)
-        hipLaunchKernelGGL(k_let_box, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sorted_keys, sorted_ids, sh.own_count(), box_ord);
-    hipLaunchKernelGGL(k_let_ends, dim3(1), dim3(64), 0, s, sorted_keys, sh.own_count(), box_ord, mine);
+        hipLaunchKernelGGL(k_let_box, grid_for(n_upper, 256), dim3(256), 0, s, sh.own_pos(), sh.acc, sorted_keys, sorted_ids, sh.own_count(),
+                           box_ord, weight_sum);
+    hipLaunchKernelGGL(k_let_ends, dim3(1), dim3(64), 0, s, sorted_keys, sh.own_count(), box_ord, weight_sum, mine);
 }
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge) {
     hipLaunchKernelGGL(k_let_edges, dim3(1), dim3(64), 0, s, ends, G, me, edge);
 }
 void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
-                    RoundB* mine) {
+                    RoundB* mine, bool balance_by_work) {
     hipLaunchKernelGGL(k_let_contrib, dim3(G), dim3(64), 0, s, w.keys, w.delta, w.base, static_cast<const Sum4*>(w.incl), sh.own_count(), info,
-                       ends, edge, G, me, mine);
+                       ends, edge, G, me, mine, w.wpre, balance_by_work ? 1 : 0);
 }
 void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds) {
     hipLaunchKernelGGL(k_let_offsets, dim3(1), dim3(64), 0, s, rb, G, global_cap, offsets, out_flags, bounds);

@@ -305,8 +305,8 @@ constexpr int kScanThreads = 256, kScanItems = 4, kScanTile = kScanThreads * kSc
 
 __device__ __forceinline__ Sum4 sum4_add(const Sum4& a, const Sum4& b) { return Sum4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
 
-struct ScanItem { Sum4 s; int c; };
-__device__ __forceinline__ ScanItem item_add(const ScanItem& a, const ScanItem& b) { return ScanItem{sum4_add(a.s, b.s), a.c + b.c}; }
+struct ScanItem { Sum4 s; int c; int w; };   // Sum4 terms, nodes emitted, weight (spatial shards; rides in the padding)
+__device__ __forceinline__ ScanItem item_add(const ScanItem& a, const ScanItem& b) { return ScanItem{sum4_add(a.s, b.s), a.c + b.c, a.w + b.w}; }
 
 // inclusive scan of one value per thread over the block (Hillis-Steele in LDS: a fixed pattern)
 template <int THREADS>
@@ -315,7 +315,7 @@ __device__ __forceinline__ ScanItem block_inclusive_scan(ScanItem v, ScanItem* l
     lds[t] = v;
     __syncthreads();
     for (int off = 1; off < THREADS; off <<= 1) {
-        ScanItem add = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
+        ScanItem add = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0, 0};
         const bool has = t >= off;
         if (has) add = lds[t - off];
         __syncthreads();
@@ -333,14 +333,15 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
                                                                      const int* __restrict__ count, signed char* __restrict__ delta,
                                                                      int* __restrict__ emit_count, Sum4* __restrict__ sums,
                                                                      int* __restrict__ flags, ScanItem* __restrict__ totals,
-                                                                     const int* __restrict__ edge) {
+                                                                     const int* __restrict__ edge, const float4* __restrict__ weight_src,
+                                                                     int* __restrict__ weight) {
     __shared__ ScanItem lds[kScanThreads];
     const int n = *count;
     // spatial shards (nbody_let.cpp): this rank's sorted bodies are a contiguous piece of the GLOBAL sorted order, and
     // its first and last body have a neighbour on another rank: edge[0] / edge[1] = levels they share with it (-1: none)
     const int edge_prev = edge ? edge[0] : -1, edge_next = edge ? edge[1] : -1;
     const int k0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    ScanItem v = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
+    ScanItem v = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0, 0};
 #pragma unroll
     for (int q = 0; q < kScanItems; ++q) {
         const int k = k0 + q;
@@ -351,10 +352,13 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
         delta[k] = (signed char)d_next;
         const int ec = max(0, d_next - d_prev) + 1;  // opened cells + the leaf
         emit_count[k] = ec;
-        const float4 p = pos[ids[k]];
+        const int id = ids[k];
+        const float4 p = pos[id];
         const Sum4 t = Sum4{double(p.w), double(p.w) * double(p.x), double(p.w) * double(p.y), double(p.w) * double(p.z)};
         sums[k] = t;
-        v = item_add(v, ScanItem{t, ec});
+        int w = 0;
+        if (weight_src) { w = body_weight(weight_src[id].w); weight[k] = w; }
+        v = item_add(v, ScanItem{t, ec, w});
     }
     v = block_inclusive_scan<kScanThreads>(v, lds);
     if (threadIdx.x == kScanThreads - 1) totals[blockIdx.x] = v;
@@ -363,7 +367,8 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
 // base[k] = exclusive scan of emit_count, incl[k] = inclusive scan of the Sum4 terms
 __global__ __launch_bounds__(kScanThreads) void k_tree_scan(const int* __restrict__ emit_count, const Sum4* __restrict__ sums,
                                                             const int* __restrict__ count, const ScanItem* __restrict__ totals,
-                                                            int* __restrict__ base, Sum4* __restrict__ incl, int* __restrict__ out_info) {
+                                                            int* __restrict__ base, Sum4* __restrict__ incl, int* __restrict__ out_info,
+                                                            int* __restrict__ weight /* in: per body; out: exclusive prefix; may be null */) {
     __shared__ ScanItem lds[kScanThreads];
     __shared__ ScanItem carry_s;
     const int n = *count;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_scan(const int* __restric
     {
         const int before = int(blockIdx.x);
         const int per = (before + kScanThreads - 1) / kScanThreads;
-        ScanItem run = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
+        ScanItem run = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0, 0};
         for (int q = 0; q < per; ++q) {
             const int b = int(threadIdx.x) * per + q;
             if (b < before) run = item_add(run, totals[b]);
@@ -385,20 +390,20 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_scan(const int* __restric
         __syncthreads();
     }
     ScanItem item[kScanItems];
-    ScanItem v = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
+    ScanItem v = ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0, 0};
 #pragma unroll
     for (int q = 0; q < kScanItems; ++q) {
-        item[q] = (k0 + q < n) ? ScanItem{sums[k0 + q], emit_count[k0 + q]} : ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0};
+        item[q] = (k0 + q < n) ? ScanItem{sums[k0 + q], emit_count[k0 + q], weight ? weight[k0 + q] : 0} : ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0, 0};
         v = item_add(v, item[q]);
     }
     const ScanItem inc = block_inclusive_scan<kScanThreads>(v, lds);
     __syncthreads();
     lds[threadIdx.x] = inc;
     __syncthreads();
-    ScanItem run = item_add(carry_s, threadIdx.x > 0 ? lds[threadIdx.x - 1] : ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0});
+    ScanItem run = item_add(carry_s, threadIdx.x > 0 ? lds[threadIdx.x - 1] : ScanItem{Sum4{0.0, 0.0, 0.0, 0.0}, 0, 0});
 #pragma unroll
     for (int q = 0; q < kScanItems; ++q) {
-        if (k0 + q < n) base[k0 + q] = run.c;
+        if (k0 + q < n) { base[k0 + q] = run.c; if (weight) weight[k0 + q] = run.w; }
         run = item_add(run, item[q]);
         if (k0 + q < n) incl[k0 + q] = run.s;
         if (k0 + q == n - 1) { out_info[0] = run.c; out_info[2] = n; }   // nodes in all; the live body count rides along (one read-back)
@@ -459,14 +464,14 @@ __global__ __launch_bounds__(256) void k_tree_own_scatter(const int* __restrict_
 
 size_t tree_build_workspace_bytes(size_t n_cap) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    return scratch_bytes(n_cap) + 3 * al(n_cap * 8) + 4 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
+    return scratch_bytes(n_cap) + 3 * al(n_cap * 8) + 5 * al(n_cap * 4) + al(n_cap) + 2 * al(n_cap * sizeof(Sum4)) + 256;
 }
 
 namespace {
 struct BuildLayout {
     void* tmp; size_t tmp_bytes;
     unsigned long long *keys_in, *keys, *keys2;
-    int *ids_in, *ids, *emit_count, *base;
+    int *ids_in, *ids, *emit_count, *base, *wpre;
     signed char* delta;
     Sum4 *sums, *incl;
 };
@@ -483,6 +488,7 @@ BuildLayout build_layout(void* workspace, size_t n_cap) {
     L.ids = reinterpret_cast<int*>(p); p += al(n_cap * 4);
     L.emit_count = reinterpret_cast<int*>(p); p += al(n_cap * 4);
     L.base = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    L.wpre = reinterpret_cast<int*>(p); p += al(n_cap * 4);
     L.delta = reinterpret_cast<signed char*>(p); p += al(n_cap);
     L.sums = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
     L.incl = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
@@ -494,7 +500,7 @@ BuildLayout build_layout(void* workspace, size_t n_cap) {
 int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
                    void* workspace, size_t n_cap, int* out_info, TreeDevWork* work) {
     const BuildLayout L = build_layout(workspace, n_cap);
-    work->keys = L.keys; work->keys2 = L.keys2; work->delta = L.delta; work->base = L.base; work->ids = L.ids; work->incl = L.incl;
+    work->keys = L.keys; work->keys2 = L.keys2; work->wpre = L.wpre; work->delta = L.delta; work->base = L.base; work->ids = L.ids; work->incl = L.incl;
     const int n = n_upper;
     if (n <= 0) { (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s); return 0; }  // (k_tree_keys clears it otherwise)
     hipLaunchKernelGGL(k_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, n, center[0], center[1], center[2], width,
@@ -510,15 +516,16 @@ int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_u
 // ints, may be null): levels the first / last sorted body shares with its neighbour on another rank (spatial shards), see
 // k_tree_delta_totals.
 int tree_scan_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info,
-                     const int* edge) {
+                     const int* edge, const float4* weight_src) {
     const BuildLayout L = build_layout(workspace, n_cap);
     const int n = n_upper;
     if (n <= 0) return 0;
     const int n_tiles = (n + kScanTile - 1) / kScanTile;
     ScanItem* totals = static_cast<ScanItem*>(L.tmp);   // (the sort is done with its scratch)
     hipLaunchKernelGGL(k_tree_delta_totals, dim3(n_tiles), dim3(kScanThreads), 0, s, L.keys, L.keys2, L.ids, pos, d_count, L.delta,
-                       L.emit_count, L.sums, out_info + 1, totals, edge);
-    hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, L.emit_count, L.sums, d_count, totals, L.base, L.incl, out_info);
+                       L.emit_count, L.sums, out_info + 1, totals, edge, weight_src, L.wpre);
+    hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, L.emit_count, L.sums, d_count, totals, L.base, L.incl, out_info,
+                       weight_src ? L.wpre : nullptr);
     return 0;
 }
 // node_offset (device, may be null): the slice is written at nodes[*node_offset ..] with its links shifted; parent /

@@ -30,6 +30,8 @@ struct State {
     int G = 1, me = 0;
     bool prune = true;
     bool rebalance = true;        // redraw the ownership bounds every step (NBODY_LET_REBALANCE=0: keep the upload's)
+    bool by_work = true;          // ... at the quantiles of the walk's visit counts (NBODY_LET_BALANCE=count: of the body count)
+    unsigned long long* d_weight_sum = nullptr;
     unsigned long long* d_bounds_scratch = nullptr;   // [G + 1] where the redrawn bounds go when they are not used
     std::vector<unsigned long long> h_bounds;   // [G + 1]
     unsigned long long* d_bounds = nullptr;
@@ -209,7 +211,7 @@ int phase1(NbodyHandle* h, State& s) {
     h->n_local = std::min<size_t>(size_t(sh.seg_cap), h->n_local + size_t(s.mig_in));
     if (tree_sort_keys(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->center, h->width, s.d_ws, s.ws_cap, s.d_tree_info, &s.work) != 0)
         return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
-    launch_ends(h->stream, sh, int(h->n_local), s.work.keys, s.work.ids, s.d_box_ord, s.d_ends + s.me);
+    launch_ends(h->stream, sh, int(h->n_local), s.work.keys, s.work.ids, s.d_box_ord, s.d_weight_sum, s.d_ends + s.me);
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
@@ -219,9 +221,9 @@ int phase2(NbodyHandle* h, State& s) {
     PhaseTimer timer(h, s, 2);
     launch_edges(h->stream, s.d_ends, s.G, s.me, s.d_edge);
     // delta, the scans: how many nodes my slice has, every body's first node, the prefix sums the spanning cells need
-    if (tree_scan_sorted(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), s.d_ws, s.ws_cap, s.d_tree_info, s.d_edge) != 0)
+    if (tree_scan_sorted(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), s.d_ws, s.ws_cap, s.d_tree_info, s.d_edge, sh.acc) != 0)
         return fail(h, NBODY_ERR_HIP, "device octree build failed");
-    launch_contrib(h->stream, sh, s.work, s.d_tree_info, s.d_ends, s.d_edge, s.G, s.me, s.d_rb + s.me);
+    launch_contrib(h->stream, sh, s.work, s.d_tree_info, s.d_ends, s.d_edge, s.G, s.me, s.d_rb + s.me, s.by_work);
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
@@ -255,6 +257,7 @@ int phase4(NbodyHandle* h, State& s, float dt, bool kick) {
     td.order = s.d_order; td.n_order = int(h->n_local);
     td.n_order_dev = sh.own_count();
     td.poison = s.d_flags;
+    td.store_work = 1;
     td.n_split = 1;
     td.split_first = s.d_split;
     td.split_n_anc = s.d_split + 2;
@@ -288,6 +291,8 @@ int create(NbodyHandle* h) {
     if ((rc = dev_alloc(h, &s.d_bounds, size_t(s.G) + 1))) return rc;
     if ((rc = dev_alloc(h, &s.d_bounds_scratch, size_t(s.G) + 1))) return rc;
     if (const char* v = std::getenv("NBODY_LET_REBALANCE")) s.rebalance = std::atoi(v) != 0;
+    if (const char* v = std::getenv("NBODY_LET_BALANCE")) s.by_work = std::strcmp(v, "count") != 0;
+    if ((rc = dev_alloc(h, &s.d_weight_sum, 1))) return rc;
     if ((rc = dev_alloc(h, &s.d_send_count, size_t(s.G)))) return rc;
     if ((rc = dev_alloc(h, &s.d_send_off, size_t(s.G) + 1))) return rc;
     if ((rc = dev_alloc(h, &s.d_mig_cursor, size_t(s.G)))) return rc;
@@ -321,7 +326,7 @@ int create(NbodyHandle* h) {
 void destroy(NbodyHandle* h) {
     State* s = h->let;
     if (!s) return;
-    void* dev[] = {s->d_bounds, s->d_bounds_scratch, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_send_off, s->d_mig_cursor, s->d_mig_matrix, s->d_dest_of, s->d_new_count, s->d_flags, s->d_box_ord,
+    void* dev[] = {s->d_bounds, s->d_bounds_scratch, s->d_weight_sum, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_send_off, s->d_mig_cursor, s->d_mig_matrix, s->d_dest_of, s->d_new_count, s->d_flags, s->d_box_ord,
                    s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_global, s->d_order, s->d_tree_info,
                    s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_send,
                    s->d_let_recv, s->d_let_matrix, h->sh.ids};
@@ -621,6 +626,11 @@ int debug_exchange(NbodyHandle* h, NbodyHandle* peer, int which) {
 }  // namespace let
 }  // namespace nbody
 
+extern "C" int nbody_debug_let_set_balance(NbodyHandle* h, int by_work) {
+    if (!h || !h->let) return NBODY_ERR_INVALID;
+    h->let->by_work = by_work != 0;
+    return NBODY_OK;
+}
 extern "C" int nbody_debug_let_set_prune(NbodyHandle* h, int prune) {
     if (!h || !h->let) return NBODY_ERR_INVALID;
     h->let->prune = prune != 0;

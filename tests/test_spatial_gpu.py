@@ -92,6 +92,8 @@ def test_migration_keeps_ownership_by_key_range(gpu, G):
     box = ((0.0, 0.0, 0.0), 2.2)
     dt = np.float32(0.05)
     sims = make_world(nb, ics, G, box, nb.Settings(0.0, 0.0, float(dt), 0.25))
+    for s in sims:
+        s.set_balance(False)    # quantiles of the body count (the default weighs the bodies by their walks' visit counts)
     key0 = host_keys(nb, ics, box)
     bounds = sims[0].let_bounds()
     assert [int(b) for b in bounds[1:G]] == [int(np.sort(key0)[min(n - 1, r * n // G)]) for r in range(1, G)]   # the upload's quantiles
@@ -193,6 +195,34 @@ def test_spatial_shards_with_bodies_that_share_all_21_levels(gpu):
     finally:
         tie.value = 64
         close(sims)
+
+
+def test_bounds_weighted_by_the_walks_visit_counts_even_out_the_work(gpu):
+    """Equal body counts are not equal work: bodies in the dense core visit more nodes.  By default the bounds are redrawn
+    at the quantiles of the last walk's per-body visit counts (they ride in acc.w through retain and migration)."""
+    nb = gpu
+    n, G = 40000, 4
+    st = nb.Settings(1.0, 0.01, 1e-3, 0.25)
+    ics = nb.plummer(n, seed=67)
+    ics["position"] += np.float32([0.37, -0.21, 0.13])       # off the octant symmetry: the key ranges get different densities
+    spread = {}
+    for by_work in (False, True):
+        sims = make_world(nb, ics, G, BOX, st)
+        for s in sims:
+            s.set_balance(by_work)
+        for _ in range(4):
+            nb.spatial_step(sims)
+        for s in sims:
+            s.reset_stats()
+        nb.spatial_step(sims)
+        visits = np.array([s.stats().node_visits for s in sims], np.float64)
+        owned = [len(s) for s in sims]
+        spread[by_work] = visits.max() / visits.mean()
+        rec, idx = nb.spatial_gather(sims, n)
+        assert np.array_equal(idx, np.arange(n))
+        close(sims)
+        print(f"balance by {'work' if by_work else 'count'}: bodies {owned}, visits max/mean {spread[by_work]:.3f}")
+    assert spread[True] < 1.03 and spread[True] < spread[False]
 
 
 def test_pruning_changes_the_volume_not_the_result(gpu):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--balance", default="work", choices=["work", "count"])
     a = ap.parse_args()
     nb = graft.load_package()
     box = ((0.0, 0.0, 0.0), 64.0)
@@ -52,8 +53,9 @@ def main():
                           shard_mode=nb.SHARD_SPATIAL) for r in range(G)]
     for s in sims:
         s.settings = st
+        s.set_balance(a.balance == "work")
         s.init()
-    for _ in range(2):
+    for _ in range(4):
         nb.spatial_step(sims)
     for s in sims:
         s.set_profiling(True)
@@ -63,11 +65,13 @@ def main():
     ranks = []
     for r, s in enumerate(sims):
         l = s.let_stats()
+        sst = s.stats()
         k = float(l.steps)
         ph = [l.phase_ms[i] / k for i in range(5)]
         ranks.append(dict(rank=r, bodies=len(s), nodes_local=l.nodes_local / k, nodes_global=l.nodes_global / k,
                           nodes_sent=l.nodes_sent / k, nodes_received=l.nodes_received / k, migrated=l.bodies_migrated / k,
                           bytes_sent=l.bytes_sent / k, bytes_allgather=l.bytes_allgather_equivalent / k,
+                          node_visits=sst.node_visits / k, accepted=sst.interactions / k,
                           phase_ms=dict(drift_retain_migrate=ph[0], append_keys_sort=ph[1], emit_slice=ph[2], finish_flag_pack=ph[3],
                                         walk_kick=ph[4]),
                           build_ms=ph[1] + ph[2] + ph[3], device_ms=sum(ph)))
@@ -83,12 +87,12 @@ def main():
     print(f"single GPU, device tree: {single['step_ms']:.3f} ms/step (walk {single['walk_ms']:.3f}, build + rest {single['build_and_rest_ms']:.3f}), "
           f"{single['tree_nodes']} nodes")
     print(f"{'rank':>4} {'bodies':>8} {'nodes':>8} {'sent':>8} {'recv':>8} {'MB sent':>8} {'MB allg':>8} | "
-          f"{'p0':>6} {'p1':>6} {'p2':>6} {'p3':>6} {'walk':>6} {'sum':>6}")
+          f"{'p0':>6} {'p1':>6} {'p2':>6} {'p3':>6} {'walk':>6} {'sum':>6} | {'Mvisits':>8}")
     for x in ranks:
         p = x["phase_ms"]
         print(f"{x['rank']:>4} {x['bodies']:>8} {x['nodes_local']:>8.0f} {x['nodes_sent']:>8.0f} {x['nodes_received']:>8.0f} "
               f"{x['bytes_sent'] / 1e6:>8.2f} {x['bytes_allgather'] / 1e6:>8.2f} | {p['drift_retain_migrate']:>6.3f} {p['append_keys_sort']:>6.3f} "
-              f"{p['emit_slice']:>6.3f} {p['finish_flag_pack']:>6.3f} {p['walk_kick']:>6.3f} {x['device_ms']:>6.3f}")
+              f"{p['emit_slice']:>6.3f} {p['finish_flag_pack']:>6.3f} {p['walk_kick']:>6.3f} {x['device_ms']:>6.3f} | {x['node_visits'] / 1e6:>8.1f}")
     if a.json:
         with open(a.json, "w") as f:
             json.dump(out, f, indent=1)
