@@ -52,7 +52,7 @@ void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned lon
                  unsigned long long* weight_sum, EndInfo* mine);
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge);
 void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
-                    RoundB* mine, bool balance_by_work);
+                    RoundB* mine, bool balance_by_work, const int* own_flags);
 void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds);
 void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
                      const int* offsets, int* top_index);

@@ -150,16 +150,37 @@ __global__ __launch_bounds__(256) void k_let_box(const float4* __restrict__ pos,
     for (int t = threadIdx.x; t < (kBoxes + 1) * 6; t += 256) red[t / 6][t % 6] = (t % 6) < 3 ? 0x7fffffff : int(0x80000000);
     __syncthreads();
     const int j = blockIdx.x * 256 + threadIdx.x;   // sorted position
-    if (j < n) {
+    const bool live = j < n;
+    int g = -1, w = 0;
+    int o[3] = {0, 0, 0};
+    if (live) {
         const int c = min(common_levels(keys[0], keys[n - 1]), kLevels - kBoxDigits);   // the deepest cell holding all my bodies
-        const int g = int((keys[j] >> (3 * (kLevels - kBoxDigits - c))) & (unsigned long long)(kBoxes - 1));
+        g = int((keys[j] >> (3 * (kLevels - kBoxDigits - c))) & (unsigned long long)(kBoxes - 1));
         const float4 p = pos[ids[j]];
-        atomicAdd(&wsum_s, body_weight(acc[ids[j]].w));   // what the body cost in the last walk (1 before the first)
-        const int o[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
+        w = body_weight(acc[ids[j]].w);   // what the body cost in the last walk (1 before the first)
+        o[0] = f2ord(p.x); o[1] = f2ord(p.y); o[2] = f2ord(p.z);
+    }
+    // sorted order: the 64 bodies of a wave nearly always share their child cell -- then one lane speaks for all
+    const int g0 = __builtin_amdgcn_readfirstlane(g);
+    if (__all(live && g == g0)) {
+        int lo[3] = {o[0], o[1], o[2]}, hi[3] = {o[0], o[1], o[2]};
+        for (int off = 32; off > 0; off >>= 1) {
+            for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], off)); hi[a] = max(hi[a], __shfl_xor(hi[a], off)); }
+            w += __shfl_xor(w, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&red[g0][a], lo[a]); atomicMax(&red[g0][3 + a], hi[a]);
+                atomicMin(&red[kBoxes][a], lo[a]); atomicMax(&red[kBoxes][3 + a], hi[a]);
+            }
+            atomicAdd(&wsum_s, w);
+        }
+    } else if (live) {
         for (int a = 0; a < 3; ++a) {
             atomicMin(&red[g][a], o[a]); atomicMax(&red[g][3 + a], o[a]);
             atomicMin(&red[kBoxes][a], o[a]); atomicMax(&red[kBoxes][3 + a], o[a]);
         }
+        atomicAdd(&wsum_s, w);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < (kBoxes + 1) * 6; t += 256) {
@@ -206,11 +227,14 @@ __global__ __launch_bounds__(64) void k_let_contrib(const unsigned long long* __
                                                     const int* __restrict__ base, const Sum4* __restrict__ incl,
                                                     const int* __restrict__ count, const int* __restrict__ info /* {n_nodes, flags} */,
                                                     const EndInfo* __restrict__ ends, const int* __restrict__ edge, int G, int me,
-                                                    RoundB* __restrict__ mine, const int* __restrict__ wpre, int by_work) {
+                                                    RoundB* __restrict__ mine, const int* __restrict__ wpre, int by_work,
+                                                    const int* __restrict__ own_flags) {
     const int r = blockIdx.x;      // the rank whose spanning cells are concerned
     const int d = threadIdx.x;     // depth
     const int n = *count;
-    if (r == 0 && d == 0) { mine->n_nodes = n > 0 ? info[0] : 0; mine->flags = info[1]; mine->pad[0] = mine->pad[1] = 0; }
+    // (what this rank has raised so far travels too: every rank ends the step with the same verdict, none is left waiting
+    // in the next collective for one that has returned an error)
+    if (r == 0 && d == 0) { mine->n_nodes = n > 0 ? info[0] : 0; mine->flags = info[1] | *own_flags; mine->pad[0] = mine->pad[1] = 0; }
     if (r == 0 && d < kMaxRanks) {
         // Next step's bounds.  The world's sorted order is the concatenation of the ranks' sorted orders, so its G-quantiles
         // are plain look-ups: quantile j sits at global position j N / G, on the rank whose run of positions contains it.
@@ -496,9 +520,9 @@ void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge) 
     hipLaunchKernelGGL(k_let_edges, dim3(1), dim3(64), 0, s, ends, G, me, edge);
 }
 void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
-                    RoundB* mine, bool balance_by_work) {
+                    RoundB* mine, bool balance_by_work, const int* own_flags) {
     hipLaunchKernelGGL(k_let_contrib, dim3(G), dim3(64), 0, s, w.keys, w.delta, w.base, static_cast<const Sum4*>(w.incl), sh.own_count(), info,
-                       ends, edge, G, me, mine, w.wpre, balance_by_work ? 1 : 0);
+                       ends, edge, G, me, mine, w.wpre, balance_by_work ? 1 : 0, own_flags);
 }
 void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds) {
     hipLaunchKernelGGL(k_let_offsets, dim3(1), dim3(64), 0, s, rb, G, global_cap, offsets, out_flags, bounds);

@@ -223,7 +223,7 @@ int phase2(NbodyHandle* h, State& s) {
     // delta, the scans: how many nodes my slice has, every body's first node, the prefix sums the spanning cells need
     if (tree_scan_sorted(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), s.d_ws, s.ws_cap, s.d_tree_info, s.d_edge, sh.acc) != 0)
         return fail(h, NBODY_ERR_HIP, "device octree build failed");
-    launch_contrib(h->stream, sh, s.work, s.d_tree_info, s.d_ends, s.d_edge, s.G, s.me, s.d_rb + s.me, s.by_work);
+    launch_contrib(h->stream, sh, s.work, s.d_tree_info, s.d_ends, s.d_edge, s.G, s.me, s.d_rb + s.me, s.by_work, s.d_flags);
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
