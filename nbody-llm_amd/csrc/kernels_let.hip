@@ -4,8 +4,10 @@
 // The tree is the one the single-shard device build makes (kernels_tree.hip: same cells, pre-order, skip links as
 // BarnesHutSimulation::build_tree, src/manual/barnes_hut.rs:143-183), but no rank ever sees all bodies:
 //   * ownership by Morton-key range: rank r holds the bodies whose 63-bit key (the orthant codes of 21 levels) lies in
-//     [bound[r], bound[r+1]); the bounds are the G-quantiles of the world's keys, redrawn every step.  Bodies on the wrong side of a bound
-//     migrate (k_let_classify / k_let_pack_migrants pack them per destination, k_let_append takes them in);
+//     [bound[r], bound[r+1]); the bounds are the G-quantiles of the world's keys -- weighted by the visit counts of the
+//     last walk, so that the ranks get equal work -- redrawn every step (k_let_contrib, k_let_offsets).  Bodies on the
+//     wrong side of a bound migrate (k_let_classify / k_let_pack_migrants pack them per destination, k_let_append takes
+//     them in);
 //   * then the GLOBAL sorted order is the concatenation of the ranks' local sorted orders, so in the build's
 //     formulation (body k opens the cells of depths delta[k-1]+1 .. delta[k]; its leaf sits at max(..)+1) only a rank's
 //     FIRST and LAST sorted body have a neighbour elsewhere: two "edge" values (k_let_edges) from an all-gather of every
@@ -15,8 +17,9 @@
 //     skip link the first node behind them: every rank works out what it adds to every earlier rank's spanning cells
 //     (k_let_contrib), one all-gather of those small tables, and everybody knows all spanning cells (k_let_finalize);
 //   * everything else is private to a rank's slice.  A partner needs a private node only if one of its bodies can get
-//     there, i.e. if it can OPEN every ancestor: k_let_open_masks / k_let_flag_pack test the ancestors against the boxes the partners' bodies lie in
-//     (opening test of barnes_hut.rs:192 with the box's nearest point) and write one list of records per partner,
+//     there, i.e. if it can OPEN every ancestor: k_let_open_masks / k_let_flag_pack test the ancestors against the
+//     boxes the partners' bodies lie in (opening test of barnes_hut.rs:192 with the box's nearest point) and write one
+//     list of records per partner,
 //     one variable-size send/recv round, k_let_scatter drops them at their global indices in the receiver's array.
 // The walk (k_bh_walk) then runs over that array as over a complete tree: every node a body visits is there.
 // Fast math, device build; node values come from f64 prefix sums over the LOCAL sorted order, so against the single-shard

@@ -2,14 +2,15 @@
 // the scheme.  A spatial handle is a SINGLE-segment shard (its own bodies only): drift, retain, the device build's
 // kernels and the walk run on it as on a one-GPU handle; what is added are five phases separated by four exchanges:
 //   phase 0  drift, retain, pick the bodies whose key left the rank's range and pack them per destination
-//   --- exchange 0: migrants (fixed-size slots, all-to-all)
-//   phase 1  take the immigrants in, keys + sort of the own bodies, first/last key and bounding box
-//   --- exchange 1: all-gather of the 48-byte end infos
-//   phase 2  edge values, delta / scans / emit of the own slice, contributions to every earlier rank's spanning cells
-//   --- exchange 2: all-gather of the spanning-cell tables (13 KB per rank)
-//   phase 3  own slice into the global-index array, all spanning cells finished, the nodes each partner can reach
-//            flagged (ancestors against its bounding box) and packed
-//   --- exchange 3: node records, variable size (the counts travel first)
+//   --- exchange 0: migrants, variable size (the G x G counts travel first: all-gather + a host synchronisation)
+//   phase 1  take the immigrants in, keys + sort of the own bodies, first/last key, boxes and weight of the own bodies
+//   --- exchange 1: all-gather of the end infos (1.6 KB per rank)
+//   phase 2  edge values, delta and the scans of the own slice, contributions to every earlier rank's spanning cells, the
+//            keys of the world's quantiles that lie on this rank (next step's bounds)
+//   --- exchange 2: all-gather of those tables (13 KB per rank)
+//   phase 3  next step's bounds, own slice emitted into the global-index array, all spanning cells finished, the nodes
+//            each partner can reach flagged (ancestors against the boxes its bodies lie in) and packed
+//   --- exchange 3: node records, variable size (counts first: all-gather + the second host synchronisation of a step)
 //   phase 4  imports dropped at their global indices, walk, kick + half drift
 // Production (`step`) does the exchanges with RCCL on the handle's stream; the tests run G handles of one process on one
 // GPU and do them as device-to-device copies (debug_phase / debug_exchange) -- same kernels, same buffers.
