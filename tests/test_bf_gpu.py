@@ -406,3 +406,20 @@ def test_energy_drift_stays_with_the_cpu_reference_trajectory(gpu, orc):
     assert abs(drift_gpu - drift_ref) < 1e-5, (drift_gpu, drift_ref)
     assert abs(drift_ref) < 1e-4
     assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 1e-5
+
+
+def test_energy_drift_over_1000_steps_at_full_size(gpu):
+    """energy drift over 1 000 steps at N = 65 536 (dt = 1e-3, eps = 1e-2, fast math; energies in
+    f64 on the device).  The leapfrog's energy error oscillates and stays below 1e-5 of |E0|; every 250 steps is looked at."""
+    nb = gpu
+    ics = nb.plummer(65536)
+    with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
+        sim.settings = nb.Settings(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
+        e0 = sum(sim.energy())
+        worst = 0.0
+        for _ in range(4):
+            sim.steps(250)
+            worst = max(worst, abs((sum(sim.energy()) - e0) / e0))
+        assert len(sim) == 65536
+    print(f"|dE/E0| over 1000 steps at N = 65536: {worst:.2e}")
+    assert worst < 1e-5
