@@ -74,9 +74,11 @@ enum {
 
 /* the reference's `F: Float` (src/shared.rs:12-44) */
 enum { NBODY_F32 = 0,  /* PointParticle<f32,3>: every path of this library */
-       NBODY_F64 = 1 }; /* PointParticle<f64,3>: one shard, strict arithmetic (math_mode is ignored), Barnes-Hut with the
-                          host build; positions, velocities, accelerations and node counts bit-equal to the reference's
-                          rounding sequence in f64 (oracle/: the same templated restatement) */
+       NBODY_F64 = 1 }; /* PointParticle<f64,3>: one shard, strict arithmetic (math_mode is ignored).  Barnes-Hut with the
+                          host build (NBODY_TREE_HOST, also what AUTO means here): positions, velocities, accelerations
+                          and node counts bit-equal to the reference's rounding sequence in f64 (oracle/: the same
+                          templated restatement); with NBODY_TREE_DEVICE the tree is built on the device (same cells,
+                          centres of mass to the last bits: node counts within 1e-6), ~4x the steps per second */
 
 /* how the bodies are dealt to the shards of a multi-GPU run */
 enum { NBODY_SHARD_INDEX = 0,   /* contiguous index blocks of the vector; positions all-gathered every step (every method) */

@@ -161,6 +161,13 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
 // level-order copy of a pre-order node array for the cooperative block walk
 size_t bfs_workspace_bytes(size_t n_cap);
 int build_bfs_layout(hipStream_t s, const float4* nodes, int n_nodes, void* workspace, size_t n_cap, float4* out);
+// F = f64 (nbody_f64.cpp): double4 bodies, Node64 records (kernels_f64.h)
+}  // namespace nbody
+namespace nbody64 { struct Node64; }
+namespace nbody {
+int build_octree_device_f64(hipStream_t s, const double4* pos, const int* d_count, int n_upper, const double center[3], double width,
+                            void* workspace, size_t n_cap, nbody64::Node64* nodes, int node_cap, int* order, int* out_info,
+                            TreeDevWork* work);
 // the build in two halves (spatial shards need the sorted keys of all ranks' ends before the second one)
 int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
                    void* workspace, size_t n_cap, int* out_info, TreeDevWork* work);

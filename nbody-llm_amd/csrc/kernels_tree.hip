@@ -25,6 +25,7 @@
 // far below an ulp of the coordinates by then) make the build report "too deep"; the one-GPU caller falls back to the
 // host build (which goes to depth 192 before it gives up), the spatial-shard caller returns NBODY_ERR_TREE_DEPTH.
 #include "kernels.h"
+#include "kernels_f64.h"   // Node64: the F = f64 instantiation of the build writes 64-byte records
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -46,14 +47,15 @@ struct Sum4Plus {
 };
 
 // the orthant codes of kLevels levels starting at level `first` (0: the sort key; kLevels: the tie-break key)
-__device__ __forceinline__ unsigned long long orthant_key(const float4 p, float cx, float cy, float cz, float width, int first) {
-    float hw = width * 0.5f;  // Bounds::new
+template <class P4, class Real>
+__device__ __forceinline__ unsigned long long orthant_key(const P4 p, Real cx, Real cy, Real cz, Real width, int first) {
+    Real hw = width * Real(0.5);  // Bounds::new
     unsigned long long key = 0;
 #pragma unroll 1
     for (int l = 0; l < first + kLevels; ++l) {
         const bool bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // get_orthant
         key = (key << 3) | (unsigned long long)((bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0));   // (the levels before `first` fall off the top)
-        hw = hw * 0.5f;                                            // create_orthant
+        hw = hw * Real(0.5);                                       // create_orthant
         cx = bx ? cx + hw : cx - hw;
         cy = by ? cy + hw : cy - hw;
         cz = bz ? cz + hw : cz - hw;
@@ -61,8 +63,21 @@ __device__ __forceinline__ unsigned long long orthant_key(const float4 p, float 
     return key & 0x7fffffffffffffffull;
 }
 
-__global__ __launch_bounds__(256) void k_tree_keys(const float4* __restrict__ pos, const int* __restrict__ count,
-                                                   int n_upper, float cx0, float cy0, float cz0, float width,
+// one node record: {com, mass | w^2, skip, hot, body} as two float4 (F = f32) or one Node64 (F = f64)
+__device__ __forceinline__ void put_node(float4* nodes, size_t i, float x, float y, float z, float m, float w2, int skip, int hot, int body) {
+    nodes[2 * i] = make_float4(x, y, z, m);
+    nodes[2 * i + 1] = make_float4(w2, __int_as_float(skip), __int_as_float(hot), __int_as_float(body));
+}
+__device__ __forceinline__ void put_node(nbody64::Node64* nodes, size_t i, double x, double y, double z, double m, double w2, int skip, int hot,
+                                         int body) {
+    nbody64::Node64 r;
+    r.x = x; r.y = y; r.z = z; r.m = m; r.w2 = w2; r.skip = skip; r.hot = hot; r.body = body; r.pad = 0; r.pad2 = 0.0;
+    nodes[i] = r;
+}
+
+template <class P4, class Real>
+__global__ __launch_bounds__(256) void k_tree_keys(const P4* __restrict__ pos, const int* __restrict__ count,
+                                                   int n_upper, Real cx0, Real cy0, Real cz0, Real width,
                                                    unsigned long long* __restrict__ keys, int* __restrict__ ids,
                                                    int* __restrict__ out_info) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -92,8 +107,9 @@ __device__ __forceinline__ int common_levels2(const unsigned long long* __restri
 // After the sort: the first body of every group of equal keys gives the group its second keys (levels 21..41) and puts
 // it in their order (insertion sort, stable: the radix sort left the ids ascending).  Groups are pairs in practice; one
 // of more than nbody_tree_max_tie bodies (64) is reported as too deep rather than sorted by a single thread.
-__global__ __launch_bounds__(256) void k_tree_ties(const float4* __restrict__ pos, const int* __restrict__ count, float cx0, float cy0,
-                                                   float cz0, float width, const unsigned long long* __restrict__ keys,
+template <class P4, class Real>
+__global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, const int* __restrict__ count, Real cx0, Real cy0,
+                                                   Real cz0, Real width, const unsigned long long* __restrict__ keys,
                                                    unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
                                                    int kMaxTie) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -118,11 +134,12 @@ __global__ __launch_bounds__(256) void k_tree_ties(const float4* __restrict__ po
 // cells x a 17-step binary search in one thread was the kernel's whole duration, 30 us).  Node idx
 // belongs to the body k with base[k] <= idx < base[k+1] (binary search); its t-th node is the cell of
 // depth delta[k-1]+1+t that the body opens, or -- the last one -- the body's leaf.
+template <class P4, class Real, class NodeT>
 __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
-                                                   const int* __restrict__ ids, const float4* __restrict__ pos,
+                                                   const int* __restrict__ ids, const P4* __restrict__ pos,
                                                    const int* __restrict__ count, const signed char* __restrict__ delta,
                                                    const int* __restrict__ base, const Sum4* __restrict__ incl,
-                                                   float width, float4* __restrict__ nodes, int node_cap,
+                                                   Real width, NodeT* __restrict__ nodes, int node_cap,
                                                    int* __restrict__ order, int* __restrict__ out_info, int want_hot,
                                                    const int* __restrict__ edge, const int* __restrict__ node_offset,
                                                    int* __restrict__ parent_out, unsigned char* __restrict__ depth_out) {
@@ -134,8 +151,7 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
         if (node_offset) { if (idx == 0) { out_info[0] = 0; out_info[2] = 0; } return; }   // (a rank without bodies adds nothing to the world's tree)
         if (idx == 0) {
             if (node_cap >= 1) {
-                nodes[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                nodes[1] = make_float4(width * width, __int_as_float(1), __int_as_float(0), __int_as_float(-1));
+                put_node(nodes, 0, Real(0), Real(0), Real(0), Real(0), width * width, 1, 0, -1);
             }
             out_info[0] = 1;
             out_info[2] = 0;
@@ -220,19 +236,18 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
         const Sum4 before = (k > 0) ? incl[k - 1] : Sum4{0.0, 0.0, 0.0, 0.0};
         const Sum4 upto = incl[j];
         const double m = upto.m - before.m;
-        float w = width;
-        for (int q = 0; q < d; ++q) w = w * 0.5f;       // create_orthant halves the width exactly
+        Real w = width;
+        for (int q = 0; q < d; ++q) w = w * Real(0.5);  // create_orthant halves the width exactly
         const int skip = off + ((j + 1 < n) ? base[j + 1] : total);
-        nodes[2 * size_t(off + idx)] = make_float4(float((upto.x - before.x) / m), float((upto.y - before.y) / m),
-                                                   float((upto.z - before.z) / m), float(m));
-        nodes[2 * size_t(off + idx) + 1] = make_float4(w * w, __int_as_float(skip), __int_as_float(hot), __int_as_float(-1));
+        put_node(nodes, size_t(off + idx), Real((upto.x - before.x) / m), Real((upto.y - before.y) / m), Real((upto.z - before.z) / m), Real(m),
+                 w * w, skip, hot, -1);
     } else {                            // the body's leaf
         const int ld = max(d_prev, d_next) + 1;
-        float w = width;
-        for (int q = 0; q < ld; ++q) w = w * 0.5f;
+        Real w = width;
+        for (int q = 0; q < ld; ++q) w = w * Real(0.5);
         const int id = ids[k];
-        nodes[2 * size_t(off + idx)] = pos[id];
-        nodes[2 * size_t(off + idx) + 1] = make_float4(w * w, __int_as_float(off + idx + 1), __int_as_float(hot), __int_as_float(id));
+        const P4 p = pos[id];
+        put_node(nodes, size_t(off + idx), p.x, p.y, p.z, p.w, w * w, off + idx + 1, hot, id);
         order[k] = id;
     }
 }
@@ -327,9 +342,10 @@ __device__ __forceinline__ ScanItem block_inclusive_scan(ScanItem v, ScanItem* l
 
 // per sorted body k: delta[k] (common levels with its right neighbour), emit_count[k] (cells it opens + its leaf), the
 // Sum4 term; per tile of kScanTile bodies: the totals of both
+template <class P4>
 __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsigned long long* __restrict__ keys,
                                                                      const unsigned long long* __restrict__ keys2,
-                                                                     const int* __restrict__ ids, const float4* __restrict__ pos,
+                                                                     const int* __restrict__ ids, const P4* __restrict__ pos,
                                                                      const int* __restrict__ count, signed char* __restrict__ delta,
                                                                      int* __restrict__ emit_count, Sum4* __restrict__ sums,
                                                                      int* __restrict__ flags, ScanItem* __restrict__ totals,
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tree_delta_totals(const unsign
         const int ec = max(0, d_next - d_prev) + 1;  // opened cells + the leaf
         emit_count[k] = ec;
         const int id = ids[k];
-        const float4 p = pos[id];
+        const P4 p = pos[id];
         const Sum4 t = Sum4{double(p.w), double(p.w) * double(p.x), double(p.w) * double(p.y), double(p.w) * double(p.z)};
         sums[k] = t;
         int w = 0;
@@ -496,20 +512,54 @@ BuildLayout build_layout(void* workspace, size_t n_cap) {
 }
 }  // namespace
 
-// First half of the build: keys and the sort.  work->keys / work->ids = the sorted (key, body) pairs.
-int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
-                   void* workspace, size_t n_cap, int* out_info, TreeDevWork* work) {
+// ---- the build's host side, for F = f32 (float4 bodies, two float4 per node) and F = f64 (double4 bodies, Node64)
+namespace {
+template <class P4, class Real>
+int sort_keys_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, const Real center[3], Real width, void* workspace, size_t n_cap,
+                int* out_info, TreeDevWork* work) {
     const BuildLayout L = build_layout(workspace, n_cap);
     work->keys = L.keys; work->keys2 = L.keys2; work->wpre = L.wpre; work->delta = L.delta; work->base = L.base; work->ids = L.ids; work->incl = L.incl;
     const int n = n_upper;
     if (n <= 0) { (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s); return 0; }  // (k_tree_keys clears it otherwise)
-    hipLaunchKernelGGL(k_tree_keys, dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, n, center[0], center[1], center[2], width,
+    hipLaunchKernelGGL((k_tree_keys<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, n, center[0], center[1], center[2], width,
                        L.keys_in, L.ids_in, out_info);
     size_t tb = L.tmp_bytes;
     if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
-    hipLaunchKernelGGL(k_tree_ties, dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width, L.keys,
-                       L.keys2, L.ids, out_info + 1, std::max(1, nbody_tree_max_tie));
+    hipLaunchKernelGGL((k_tree_ties<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width,
+                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, nbody_tree_max_tie));
     return 0;
+}
+template <class P4>
+int scan_sorted_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info, const int* edge,
+                  const float4* weight_src) {
+    const BuildLayout L = build_layout(workspace, n_cap);
+    const int n = n_upper;
+    if (n <= 0) return 0;
+    const int n_tiles = (n + kScanTile - 1) / kScanTile;
+    ScanItem* totals = static_cast<ScanItem*>(L.tmp);   // (the sort is done with its scratch)
+    hipLaunchKernelGGL((k_tree_delta_totals<P4>), dim3(n_tiles), dim3(kScanThreads), 0, s, L.keys, L.keys2, L.ids, pos, d_count, L.delta,
+                       L.emit_count, L.sums, out_info + 1, totals, edge, weight_src, L.wpre);
+    hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, L.emit_count, L.sums, d_count, totals, L.base, L.incl, out_info,
+                       weight_src ? L.wpre : nullptr);
+    return 0;
+}
+template <class P4, class Real, class NodeT>
+int emit_nodes_t(hipStream_t s, const P4* pos, const int* d_count, Real width, void* workspace, size_t n_cap, NodeT* nodes, int node_cap,
+                 int slice_cap, int* order, int* out_info, int want_hot, const int* edge, const int* node_offset, int* parent,
+                 unsigned char* depth) {
+    const BuildLayout L = build_layout(workspace, n_cap);
+    // one thread per node; their number is known on the device only, so one per node the slice can have
+    // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
+    hipLaunchKernelGGL((k_tree_emit<P4, Real, NodeT>), dim3((std::max(1, slice_cap) + 255) / 256), dim3(256), 0, s, L.keys, L.keys2, L.ids, pos,
+                       d_count, L.delta, L.base, L.incl, width, nodes, node_cap, order, out_info, want_hot, edge, node_offset, parent, depth);
+    return 0;
+}
+}  // namespace
+
+// First half of the build: keys and the sort.  work->keys / work->ids = the sorted (key, body) pairs.
+int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
+                   void* workspace, size_t n_cap, int* out_info, TreeDevWork* work) {
+    return sort_keys_t<float4, float>(s, pos, d_count, n_upper, center, width, workspace, n_cap, out_info, work);
 }
 
 // Second half: delta and the scans (out_info[0] = nodes in all, out_info[2] = bodies), then the emit.  edge (device, 2
@@ -517,29 +567,16 @@ int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_u
 // k_tree_delta_totals.
 int tree_scan_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info,
                      const int* edge, const float4* weight_src) {
-    const BuildLayout L = build_layout(workspace, n_cap);
-    const int n = n_upper;
-    if (n <= 0) return 0;
-    const int n_tiles = (n + kScanTile - 1) / kScanTile;
-    ScanItem* totals = static_cast<ScanItem*>(L.tmp);   // (the sort is done with its scratch)
-    hipLaunchKernelGGL(k_tree_delta_totals, dim3(n_tiles), dim3(kScanThreads), 0, s, L.keys, L.keys2, L.ids, pos, d_count, L.delta,
-                       L.emit_count, L.sums, out_info + 1, totals, edge, weight_src, L.wpre);
-    hipLaunchKernelGGL(k_tree_scan, dim3(n_tiles), dim3(kScanThreads), 0, s, L.emit_count, L.sums, d_count, totals, L.base, L.incl, out_info,
-                       weight_src ? L.wpre : nullptr);
-    return 0;
+    return scan_sorted_t<float4>(s, pos, d_count, n_upper, workspace, n_cap, out_info, edge, weight_src);
 }
 // node_offset (device, may be null): the slice is written at nodes[*node_offset ..] with its links shifted; parent /
 // depth (may be null): per node of the slice, see k_tree_emit
 int tree_emit_nodes(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
                     float4* nodes, int node_cap, int slice_cap, int* order, int* out_info, int want_hot, const int* edge,
                     const int* node_offset, int* parent, unsigned char* depth) {
-    const BuildLayout L = build_layout(workspace, n_cap);
     (void)n_upper;
-    // one thread per node; their number is known on the device only, so one per node the slice can have
-    // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
-    hipLaunchKernelGGL(k_tree_emit, dim3((std::max(1, slice_cap) + 255) / 256), dim3(256), 0, s, L.keys, L.keys2, L.ids, pos, d_count, L.delta,
-                       L.base, L.incl, width, nodes, node_cap, order, out_info, want_hot, edge, node_offset, parent, depth);
-    return 0;
+    return emit_nodes_t<float4, float, float4>(s, pos, d_count, width, workspace, n_cap, nodes, node_cap, slice_cap, order, out_info, want_hot, edge,
+                                               node_offset, parent, depth);
 }
 int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
                      float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge) {
@@ -555,6 +592,16 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
                         int* out_info, TreeDevWork* work, int want_hot) {
     if (tree_sort_keys(s, pos, d_count, n_upper, center, width, workspace, n_cap, out_info, work) != 0) return -1;
     return tree_emit_sorted(s, pos, d_count, n_upper, width, workspace, n_cap, nodes, node_cap, order, out_info, want_hot, nullptr);
+}
+// The same for F = f64: keys from the reference's recurrences in double, centres of mass from the same f64 prefix sums
+// (against the reference's sequential f64 folds they differ in the last bits only), 64-byte node records.
+int build_octree_device_f64(hipStream_t s, const double4* pos, const int* d_count, int n_upper, const double center[3], double width,
+                            void* workspace, size_t n_cap, nbody64::Node64* nodes, int node_cap, int* order, int* out_info,
+                            TreeDevWork* work) {
+    if (sort_keys_t<double4, double>(s, pos, d_count, n_upper, center, width, workspace, n_cap, out_info, work) != 0) return -1;
+    if (scan_sorted_t<double4>(s, pos, d_count, n_upper, workspace, n_cap, out_info, nullptr, nullptr) != 0) return -1;
+    return emit_nodes_t<double4, double, nbody64::Node64>(s, pos, d_count, width, workspace, n_cap, nodes, node_cap, node_cap, order, out_info, 0,
+                                                          nullptr, nullptr, nullptr, nullptr);
 }
 
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,

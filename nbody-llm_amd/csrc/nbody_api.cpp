@@ -965,7 +965,10 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     h->cfg = *cfg;
     if (h->cfg.tree_build == NBODY_TREE_AUTO)   // the bit-exact path keeps the reference's (host) build
         h->cfg.tree_build = cfg->math_mode == NBODY_MATH_FAST ? NBODY_TREE_DEVICE : NBODY_TREE_HOST;
-    if (h->cfg.dtype == NBODY_F64) { h->cfg.tree_build = NBODY_TREE_HOST; h->cfg.math_mode = NBODY_MATH_STRICT; }   // what F = f64 runs
+    if (h->cfg.dtype == NBODY_F64) {   // what F = f64 runs: the strict kernels; the reference's exact tree unless the device build is asked for
+        if (h->cfg.tree_build != NBODY_TREE_DEVICE) h->cfg.tree_build = NBODY_TREE_HOST;
+        h->cfg.math_mode = NBODY_MATH_STRICT;
+    }
     if (h->cfg.shard_mode == NBODY_SHARD_SPATIAL) h->cfg.tree_build = NBODY_TREE_DEVICE;
     cfg = &h->cfg;
     h->device = dev;

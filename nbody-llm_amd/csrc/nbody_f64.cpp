@@ -39,6 +39,14 @@ struct State {
     int stack_levels = 0;
     double* d_energy = nullptr;
     size_t energy_blocks = 0;
+    // device-side build (NBODY_TREE_DEVICE): kernels_tree.hip instantiated for double
+    void* d_tree_ws = nullptr;
+    size_t tree_ws_cap = 0;    // bodies the workspace is sized for
+    int* d_tree_info = nullptr;   // [4] {nodes, flags, bodies}
+    int* h_tree_info = nullptr;   // pinned
+    nbody::TreeDevWork tree_work;
+    bool tree_on_device = false;  // where the last tree lives (nbody_tree_export)
+    size_t dev_nodes = 0;
 };
 
 namespace {
@@ -119,8 +127,85 @@ int bf_forces(NbodyHandle* h, State& s) {
     return NBODY_OK;
 }
 
+int ensure_stack(NbodyHandle* h, State& s, int levels) {   // the nested sums' stack: one entry per open cell on the lane's path
+    const size_t lanes = (size_t(s.d.cap) + 255) / 256 * 256;
+    if (lanes > s.stack_lanes || levels > s.stack_levels) {
+        if (s.d_stack) (void)hipFree(s.d_stack);
+        s.d_stack = nullptr; s.stack_lanes = 0; s.stack_levels = 0;
+        const int lv = std::max(levels + 8, 32);
+        HIP_TRY(h, hipMalloc(&s.d_stack, lanes * size_t(lv) * sizeof(Open64)));
+        s.stack_lanes = lanes; s.stack_levels = lv;
+    }
+    return NBODY_OK;
+}
+
+// The tree built on the device (NBODY_TREE_DEVICE; kernels_tree.hip for double): no positions to the host, no nodes
+// back.  Same cells, pre-order and skip links as the host build; centres of mass from f64 prefix sums instead of the
+// reference's sequential f64 folds (last bits).  *fell_back: coincident bodies / > 42 levels -> the caller builds on the host.
+int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
+    *fell_back = false;
+    auto t0 = clk::now();
+    const size_t cap = size_t(s.d.cap);
+    if (s.tree_ws_cap < cap) {
+        if (s.d_tree_ws) (void)hipFree(s.d_tree_ws);
+        s.d_tree_ws = nullptr; s.tree_ws_cap = 0;
+        HIP_TRY(h, hipMalloc(&s.d_tree_ws, nbody::tree_build_workspace_bytes(cap)));
+        s.tree_ws_cap = cap;
+    }
+    if (!s.d_tree_info) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_tree_info), 4 * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.h_tree_info), 4 * sizeof(int), hipHostMallocDefault));
+    }
+    if (cap > s.order_cap) {
+        if (s.d_order) (void)hipFree(s.d_order);
+        s.d_order = nullptr; s.order_cap = 0;
+        HIP_TRY(h, hipMalloc(&s.d_order, cap * sizeof(int)));
+        s.order_cap = cap;
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (s.node_cap < 2 * s.n_local + 64) {
+            if (s.d_nodes) (void)hipFree(s.d_nodes);
+            s.d_nodes = nullptr; s.node_cap = 0;
+            const size_t want = std::max<size_t>(2 * s.n_local + 64, s.dev_nodes + s.dev_nodes / 4 + 1024);
+            HIP_TRY(h, hipMalloc(&s.d_nodes, want * sizeof(Node64)));
+            s.node_cap = want;
+        }
+        if (nbody::build_octree_device_f64(h->stream, s.d.pos, s.d.count, int(s.n_local), s.center, s.width, s.d_tree_ws, s.tree_ws_cap, s.d_nodes,
+                                           int(std::min<size_t>(s.node_cap, 0x7fffffff)), s.d_order, s.d_tree_info, &s.tree_work) != 0)
+            return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
+        HIP_TRY(h, hipMemcpyAsync(s.h_tree_info, s.d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (s.h_tree_info[1] & 1) { *fell_back = true; return NBODY_OK; }
+        if (!(s.h_tree_info[1] & 2)) break;
+        s.dev_nodes = size_t(s.h_tree_info[0]);   // the array was too small: the build says how many it needs
+        s.node_cap = 0;
+        if (attempt == 1) return fail(h, NBODY_ERR_CAPACITY, "device octree build: node array too small twice");
+    }
+    s.dev_nodes = size_t(s.h_tree_info[0]);
+    s.n_local = size_t(s.h_tree_info[2]);
+    s.count_dirty = false;
+    s.tree_on_device = true;
+    h->stats.tree_build_ms += ms_since(t0);
+    h->stats.tree_nodes = s.dev_nodes;
+    const bool direct = h->cfg.leaf_mode == NBODY_LEAF_DIRECT;
+    if (!direct) { int rc = ensure_stack(h, s, 45); if (rc) return rc; }   // (the device build goes to 42 levels)
+    {
+        ForceTimer t(h);
+        launch_bh_walk(h->stream, s.d, s.d_nodes, int(s.dev_nodes), s.d_order, int(s.n_local), s.g, s.g_soft * s.g_soft, s.theta2, h->d_counters,
+                       direct ? 1 : 0, s.d_stack, s.stack_lanes);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return NBODY_OK;
+}
+
 // BarnesHutSimulation::update_forces (barnes_hut.rs:250-263): rebuild the tree (host, f64), one walk per body
 int bh_forces(NbodyHandle* h, State& s) {
+    if (h->cfg.tree_build == NBODY_TREE_DEVICE) {
+        bool fell_back = false;
+        int rc = bh_forces_device(h, s, &fell_back);
+        if (rc || !fell_back) return rc;
+    }
+    s.tree_on_device = false;
     auto t0 = clk::now();
     if (s.n_local) HIP_TRY(h, hipMemcpyAsync(s.h_pos, s.d.pos, s.n_local * sizeof(double4), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -154,17 +239,7 @@ int bh_forces(NbodyHandle* h, State& s) {
     if (s.tree.n_order) HIP_TRY(h, hipMemcpyAsync(s.d_order, s.tree.order, s.tree.n_order * sizeof(int), hipMemcpyHostToDevice, h->stream));
     h->stats.tree_copy_ms += copy_ms + ms_since(t2);
     const bool direct = h->cfg.leaf_mode == NBODY_LEAF_DIRECT;
-    if (!direct) {   // the nested sums' stack: one entry per open cell on the lane's path, i.e. the tree's depth
-        const size_t lanes = (size_t(s.d.cap) + 255) / 256 * 256;
-        const int levels = s.tree.max_depth + 2;
-        if (lanes > s.stack_lanes || levels > s.stack_levels) {
-            if (s.d_stack) (void)hipFree(s.d_stack);
-            s.d_stack = nullptr; s.stack_lanes = 0; s.stack_levels = 0;
-            const int lv = std::max(levels + 8, 32);
-            HIP_TRY(h, hipMalloc(&s.d_stack, lanes * size_t(lv) * sizeof(Open64)));
-            s.stack_lanes = lanes; s.stack_levels = lv;
-        }
-    }
+    if (!direct) { int rc = ensure_stack(h, s, s.tree.max_depth + 2); if (rc) return rc; }   // the tree's depth
     {
         ForceTimer t(h);
         launch_bh_walk(h->stream, s.d, s.d_nodes, int(s.tree.n_nodes), s.d_order, int(s.tree.n_order), s.g, s.g_soft * s.g_soft, s.theta2,
@@ -234,9 +309,9 @@ void destroy(NbodyHandle* h) {
     if (!s) return;
     s->tree.clear();
     void* dev[] = {s->d.pos, s->d.vel, s->d.acc, s->d.count, s->d.escaped, s->d.keep, s->d.tile_state, s->d.epoch, s->d.inter,
-                   s->d_aos, s->d_nodes, s->d_order, s->d_stack, s->d_energy};
+                   s->d_aos, s->d_nodes, s->d_order, s->d_stack, s->d_energy, s->d_tree_ws, s->d_tree_info};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {s->h_count, s->h_aos, s->h_pos};
+    void* host[] = {s->h_count, s->h_aos, s->h_pos, s->h_tree_info};
     for (void* p : host) if (p) (void)hipHostFree(p);
     delete s;
     h->f64 = nullptr;
@@ -445,12 +520,18 @@ int energy(NbodyHandle* h, double* kinetic, double* potential) {
 
 int tree_export(NbodyHandle* h, double* com_mass, double* width, int32_t* skip, size_t cap, size_t* n_nodes) {
     State& s = *h->f64;
-    const size_t n = s.tree.n_nodes;
+    const size_t n = s.tree_on_device ? s.dev_nodes : s.tree.n_nodes;
     if (n_nodes) *n_nodes = n;
     if (!com_mass && !width && !skip) return NBODY_OK;
     if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "tree export buffer too small");
+    std::vector<nbody::NodeRecT<double>> from_device;
+    if (s.tree_on_device) {
+        from_device.resize(n);
+        if (n) HIP_TRY(h, hipMemcpy(from_device.data(), s.d_nodes, n * sizeof(Node64), hipMemcpyDeviceToHost));
+    }
+    const nbody::NodeRecT<double>* nodes = s.tree_on_device ? from_device.data() : s.tree.nodes;
     for (size_t i = 0; i < n; ++i) {
-        const nbody::NodeRecT<double>& r = s.tree.nodes[i];
+        const nbody::NodeRecT<double>& r = nodes[i];
         if (com_mass) { com_mass[4 * i] = r.a.x; com_mass[4 * i + 1] = r.a.y; com_mass[4 * i + 2] = r.a.z; com_mass[4 * i + 3] = r.a.m; }
         if (width) width[i] = std::sqrt(r.b.w2);  // exact: w2 is the rounded square of the width
         if (skip) skip[i] = r.b.skip;

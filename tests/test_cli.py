@@ -25,7 +25,7 @@ def test_cli_rejects_unknown_flags():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--tree", "device"], ["--tree", "host"], ["--method", "bf", "--ic", "plummer"], ["--dtype", "f64"],
+@pytest.mark.parametrize("extra", [[], ["--tree", "device"], ["--tree", "host"], ["--method", "bf", "--ic", "plummer"], ["--dtype", "f64"], ["--dtype", "f64", "--tree", "device"],
                                    ["--dtype", "f64", "--method", "bf", "--ic", "plummer"]])
 def test_cli_reference_argv_and_output_lines(gpu, extra):
     r = subprocess.run([CLI, "-t", "4", "-n", "3000", "--steps", "50"] + extra, capture_output=True, text=True, timeout=300)

@@ -208,3 +208,59 @@ def test_f64_tracks_f32(gpu):
             out.append(sim.get_points())
     assert rel_err(out[0]["acceleration"], out[1]["acceleration"]) < 1e-5
     assert np.abs(out[0]["position"].astype(np.float64) - out[1]["position"]).max() < 3e-5   # (bodies out to radius 10: f32 ulp 1e-6, 10 steps)
+
+
+@pytest.mark.parametrize("leaf", ["reference", "direct"])
+@pytest.mark.parametrize("n,theta2", [(1, 0.25), (2, 0.25), (9, 1.0), (1000, 0.25), (20000, 0.25)])
+def test_barnes_hut_f64_device_tree(gpu, orc, n, theta2, leaf):
+    """NBODY_TREE_DEVICE on an f64 handle (kernels_tree.hip instantiated for double): the same cells, pre-order, skip
+    links, widths and leaves as the oracle's f64 tree, bit for bit; centres of mass from f64 prefix sums instead of the
+    reference's sequential f64 folds (1e-13); the strict f64 walk on it visits the same nodes unless an opening test sits
+    within that rounding of its threshold."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=theta2)
+    ics = nb.plummer(n, seed=53, f64=True)
+    ref = ics.copy().astype(orc.P64)
+    lm = 1 if leaf == "direct" else 0
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=4, leaf_mode=lm)
+    rt = orc.bh_build_tree(ics.astype(orc.P64), BOX[0], BOX[1])
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, tree_build=nb.TREE_DEVICE, leaf_mode=nb.LEAF_DIRECT if lm else nb.LEAF_REFERENCE) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+        t = sim.tree()
+    assert s.tree_nodes == len(rt["skip"]) and np.array_equal(t["skip"], rt["skip"]) and eq(t["width"], rt["width"])
+    leaves = rt["nchild"] == 0
+    assert eq(t["com_mass"][leaves], rt["com_mass"][leaves])
+    assert np.abs(t["com_mass"][:, :3] - rt["com_mass"][:, :3]).max(initial=0.0) < 1e-12 * BOX[1]
+    # (the reference's own sequential fold over n terms carries up to n * 2^-53 of rounding: the bound on the difference)
+    assert np.abs(t["com_mass"][:, 3] - rt["com_mass"][:, 3]).max(initial=0.0) < max(4e-15, n * 2.3e-16)
+    assert abs(int(s.interactions) - acc_n) <= max(1, 1e-6 * acc_n) and abs(int(s.node_visits) - vis_n) <= max(1, 1e-6 * vis_n)
+    scale = np.abs(ref["acceleration"]).max() or 1.0
+    err = np.abs(got["acceleration"] - ref["acceleration"]).max(axis=1) / scale
+    assert np.count_nonzero(err > 1e-11) <= 1 and err.max(initial=0.0) < 1e-3
+
+
+def test_barnes_hut_f64_device_tree_trajectory_and_close_pairs(gpu, orc):
+    """8 steps with escapes in a tight box, with a pair of bodies 1e-9 apart (they share all 21 levels of the first keys:
+    the second keys order them): survivors equal the oracle's, positions to 1e-12."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 2.0)
+    sd = dict(g=1.0, g_soft=0.05, dt=2e-2, theta2=0.5)
+    ics = nb.plummer(3000, seed=54, f64=True)
+    ics["position"][17] = ics["position"][5] + 1e-9
+    ics["velocity"][17] = ics["velocity"][5]
+    ref = ics.copy().astype(orc.P64)
+    with nb.Simulation(ics, *box, method=nb.BARNES_HUT, tree_build=nb.TREE_DEVICE) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.init()
+        for _ in range(8):
+            sim.step()
+            ref, _, _ = orc.bh_step_by(ref, sd, box[0], box[1], sd["dt"], threads=2)
+            assert len(sim) == len(ref)
+        got = sim.get_points()
+        depth = np.log2(box[1] / sim.tree()["width"].min())
+    assert len(ref) < 2800 and depth > 22
+    assert np.abs(got["position"] - ref["position"]).max() < 1e-11
+    assert np.array_equal(got["mass"], ref["mass"])
