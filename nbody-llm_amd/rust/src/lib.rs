@@ -104,6 +104,8 @@ pub enum TreeBuild {
 pub struct HipOptions {
     pub math_mode: MathMode,
     pub leaf_mode: LeafMode,
+    /// Barnes-Hut tree: Auto = device for f32 fast math, host otherwise (F = f64: host = bit-exact; Device = same cells,
+    /// centres of mass to their last bits, about 4x the steps per second)
     pub tree_build: TreeBuild,
     /// octree-build threads (the reference's `-t`, src/main.rs:34-35); 0 = all
     pub host_threads: i32,
