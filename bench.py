@@ -50,8 +50,9 @@ N_CU = 256
 # which parity tests cover the kernel a given line times (say so in the line)
 PARITY = {
     ("bf", "fast"): "fast math, tolerance not bit-exactness: tests/test_bf_gpu.py (acc <= 1e-5 of max|acc| vs the f32 oracle at "
-                    "N = 65 536; <= 3e-5 vs the bit-exact strict kernel; pos <= 1e-4 after 100 steps; |dE/E| < 1e-5 over 50 steps, "
-                    "an absolute bound -- the CPU oracle needs ~9 s per step at this N, no CPU trajectory is run)",
+                    "N = 65 536; <= 3e-5 vs the bit-exact strict kernel; pos <= 1e-4 after 100 steps; |dE/E0| < 1e-5 over 50 and "
+                    "over 1 000 steps at N = 65 536 (absolute: a CPU step takes ~9 s there), and within 1e-5 of the CPU oracle "
+                    "trajectory's drift at N = 8 192)",
     ("bf", "strict"): "strict math: bit-exact vs the oracle (tests/test_bf_gpu.py, tests/test_golden.py)",
     ("bh", "fast"): "fast math: node counts exact, acc <= 1e-5 of max|acc| vs the oracle (tests/test_bh_gpu.py); device tree: "
                     "structure bit-equal, counts within 1e-3 (tests/test_bh_device_tree_gpu.py)",
@@ -76,7 +77,9 @@ def parse():
     ap.add_argument("--no-bh", action="store_true", help="default line without the configs[2] object")
     ap.add_argument("--spatial-n", type=int, default=1 << 22, help="N > 1 GPUs: bodies of the configs[4] object (0: leave it out)")
     ap.add_argument("--spatial-steps", type=int, default=10)
-    ap.add_argument("--spatial-timeout", type=float, default=300.0, help="seconds before the configs[4] object is given up")
+    ap.add_argument("--spatial-timeout", type=float, default=300.0, help="seconds before the configs[3]/configs[4] objects are given up")
+    ap.add_argument("--large-n", type=int, default=1 << 20, help="N > 1 GPUs: bodies of the configs[3] object (0: leave it out)")
+    ap.add_argument("--large-steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=20250523)
     return ap.parse_args()
 
@@ -382,11 +385,13 @@ def main():
     # configs[4] beside the metric's line when there is more than one GPU: Barnes-Hut over spatial shards.  Its RCCL
     # exchange runs with > 1 rank only here (a one-GPU box cannot rehearse it), so it is fenced: an error or a rank that
     # does not come back within --spatial-timeout leaves a note in the line instead of taking the metric with it.
-    if args.workload == "bf" and world > 1 and not args.no_bh and args.spatial_n > 0:
+    extras = world > 1 or (dist is not None and os.environ.get("NBODY_BENCH_FORCE_EXTRAS"))   # (the env switch: a 1-rank rehearsal of this block)
+    if args.workload == "bf" and extras and not args.no_bh and (args.spatial_n > 0 or args.large_n > 0):
         import threading
 
         def give_up():
             if rank == 0:
+                result.setdefault("bf_large", {"error": f"no result within {args.spatial_timeout:.0f} s"})
                 result["bh_spatial"] = {"error": f"no result within {args.spatial_timeout:.0f} s"}
                 result["cpu_baseline"] = None
                 os.write(json_fd if json_fd is not None else 1, (json.dumps(result) + "\n").encode())
@@ -395,9 +400,39 @@ def main():
         guard = threading.Timer(args.spatial_timeout, give_up)
         guard.daemon = True
         guard.start()
+        # configs[3]: brute force at 2^20 bodies over the same index-block shards as the metric's line
+        big = None
+        if args.large_n > 0:
+            try:
+                import copy
+                a3 = copy.copy(args)
+                a3.steps, a3.warmup = args.large_steps, 1
+                e3, s3, _ = run(nb, a3, "bf", args.tree, nb.plummer(args.large_n, seed=args.seed), box, st, rank, world, local_rank, dist, ident_fn)
+                big = {"elapsed": e3, "interactions": float(s3.interactions), "kernel_ms": s3.force_kernel_ms / max(1.0, float(s3.force_launches))}
+            except Exception as e:  # noqa: BLE001
+                big = {"error": f"{type(e).__name__}: {e}"}
+            bigs = [None] * world
+            dist.all_gather_object(bigs, big)
+            if rank == 0:
+                bad = [b for b in bigs if b is None or "error" in b]
+                if bad:
+                    result["bf_large"] = {"error": (bad[0] or {}).get("error", "a rank returned nothing")}
+                else:
+                    el = max(b["elapsed"] for b in bigs)
+                    result["bf_large"] = {
+                        "workload": f"configs[3]: {args.large_n}-body brute force, {world} index-block shards, RCCL all-gather of positions + "
+                                    "one send/recv round of partial sums per step",
+                        "ms_per_step": 1e3 * el / args.large_steps, "steps_per_sec": args.large_steps / el,
+                        "interactions_per_sec": sum(b["interactions"] for b in bigs) / el, "steps": args.large_steps,
+                        "cross_kernel_ms_per_rank": [b["kernel_ms"] for b in bigs],
+                        "parity": PARITY[("bf", args.math)],
+                    }
         rec = None
         try:
-            rec = run_spatial(nb, args, box, dict(st, theta2=theta2), rank, world, local_rank, dist, ident_fn)
+            if args.spatial_n > 0:
+                rec = run_spatial(nb, args, box, dict(st, theta2=theta2), rank, world, local_rank, dist, ident_fn)
+            else:
+                rec = {"skipped": True}
         except Exception as e:  # noqa: BLE001 -- whatever it is, the metric's line must still go out
             rec = {"error": f"{type(e).__name__}: {e}"}
         recs = [None] * world
@@ -405,7 +440,9 @@ def main():
         guard.cancel()
         if rank == 0:
             bad = [r for r in recs if r is None or "error" in r]
-            if bad:
+            if all(r and r.get("skipped") for r in recs):
+                pass
+            elif bad:
                 result["bh_spatial"] = {"error": (bad[0] or {}).get("error", "a rank returned nothing")}
             else:
                 el = max(r["elapsed"] for r in recs)
