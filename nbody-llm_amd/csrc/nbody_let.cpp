@@ -18,9 +18,7 @@
 #include "kernels_let.h"
 
 #include <algorithm>
-#include <chrono>
 #include <cstring>
-#include <numeric>
 
 extern "C" int nbody_bh_walk_split;
 
@@ -73,7 +71,6 @@ struct State {
     int* h_pin = nullptr;         // pinned scratch [G*G + 64]
     TreeDevWork work;
     NbodyLetStats st{};
-    size_t n_at_upload = 0;
     std::vector<int> recv_n;      // emulation / production: records received from each rank this pass
     hipEvent_t ev[10] = {};       // begin/end of the five phases (nbody_set_profiling)
     bool ev_made = false, ev_live = false;
@@ -246,7 +243,6 @@ int phase3(NbodyHandle* h, State& s) {
 }
 
 // the walk over the assembled array (+ kick + half drift when this is a step)
-struct SplitInit { int first0, first1, n_anc0, pad; };
 int phase4(NbodyHandle* h, State& s, float dt, bool kick) {
     Shard& sh = h->sh;
     PhaseTimer timer(h, s, 4);
@@ -392,7 +388,6 @@ int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // own[] and the staging are reused
     h->count_dirty = false;
     h->first_global = 0; h->n_at_upload = m;
-    s.n_at_upload = n;
     return NBODY_OK;
 }
 
