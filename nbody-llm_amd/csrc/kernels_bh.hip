@@ -40,7 +40,8 @@ struct WalkSplit {
     const int* first;        // [n_seg + 1] node index where each segment starts; first[n_seg] = n_nodes
     const int* anc;          // [n_seg][kMaxAnc] ancestors of first[k], root first
     const int* n_anc;        // [n_seg]
-    float4* planes;          // [n_seg][plane_stride] partial accelerations (n_seg > 1)
+    float4* planes;          // [n_seg][plane_stride] partial accelerations (n_seg > 1), indexed by the body's place in `order`
+                             // (tree order): the walk's lanes and the reduction's both touch consecutive entries
     size_t plane_stride;
     int diag_first;          // k_bh_walk: segments of a body group in order of distance from its own place in the tree
     const int* poison;       // unsynchronised steps: != 0 -> do nothing (Shard::poison); may be null
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
                 i = i + 1;
             }
         }
-        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] =
+        *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) =
             make_float4(ax, ay, az, split.store_work ? float(n_vis) : 0.f);  // :260
     }
     if (DBG) {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __re
         const bool wants_children = active && !accept;
         i = __builtin_amdgcn_readfirstlane(__ballot(wants_children) != 0ull ? i + 1 : __float_as_int(B.y));
     }
-    if (live) (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+    if (live) *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) = make_float4(ax, ay, az, 0.f);  // :260
     for (int off = 32; off > 0; off >>= 1) {
         n_acc += __shfl_down(n_acc, off);
         n_vis += __shfl_down(n_vis, off);
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_pair(const NodeDev* __re
         i = pair_from_even(next);
     }
     if (live && !half)
-        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] =
+        *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + tb : acc + b) =
             make_float4(ax, ay, az, split.store_work ? float(n_vis) : 0.f);  // :260
     if (half) { n_acc = 0; n_vis = 0; }
     for (int off = 32; off > 0; off >>= 1) {
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(64) void k_bh_walk_coop(const NodeDev* __restrict__
         n_acc += unsigned(__popcll(__builtin_amdgcn_ballot_w64(accept)));
         i = __builtin_amdgcn_ballot_w64(open) != 0ull ? i + 1 : skip;
     }
-    if (live) (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+    if (live) *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) = make_float4(ax, ay, az, 0.f);  // :260
     if (DBG) {   // per wave: start, end (100 MHz ticks), iterations | window fills << 24 | entry replay ticks << 44
         const unsigned w = blockIdx.y * gridDim.x + blockIdx.x;
         if (lane == 0 && w < 65536) {
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(64) void k_bh_walk_block(const NodeDev* __restrict_
             }
         }
     }
-    if (live) (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] = make_float4(ax, ay, az, 0.f);  // :260
+    if (live) *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) = make_float4(ax, ay, az, 0.f);  // :260
     if (DBG) {   // per wave: start, end (100 MHz ticks), children tested | blocks fetched << 24
         const unsigned w = blockIdx.y * gridDim.x + blockIdx.x;
         if (lane == 0 && w < 65536) {
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk_lds(const NodeDev* __restrict
                 u = l_open;
             }
         }
-        (split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride : acc)[b] =
+        *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) =
             make_float4(ax, ay, az, split.store_work ? float(n_vis) : 0.f);  // :260
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ pl
     const int b = order[t];
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int k = 0; k < n_seg; ++k) {  // segment order = the order the single walk adds them in
-        const float4 v = planes[size_t(k) * plane_stride + b];
+        const float4 v = planes[size_t(k) * plane_stride + t];   // (by tree-order position: coalesced; by body it was a gather, 18 us)
         sx += v.x; sy += v.y; sz += v.z;
     }
     acc[b] = make_float4(sx, sy, sz, 0.f);
