@@ -289,6 +289,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if os.environ.get("NBODY_BENCH_DEVICE"):   # rehearsal on a box with fewer GPUs than ranks (if RCCL accepts it)
+        local_rank = int(os.environ["NBODY_BENCH_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
