@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--spatial-timeout", type=float, default=300.0, help="seconds before the configs[3]/configs[4] objects are given up")
     ap.add_argument("--large-n", type=int, default=1 << 20, help="N > 1 GPUs: bodies of the configs[3] object (0: leave it out)")
     ap.add_argument("--large-steps", type=int, default=5)
+    ap.add_argument("--main-timeout", type=float, default=600.0, help="N > 1 GPUs: seconds before the metric's own run is declared stuck")
     ap.add_argument("--seed", type=int, default=20250523)
     return ap.parse_args()
 
@@ -326,6 +327,23 @@ def main():
         dist.broadcast_object_list(ident, src=0)
         return ident[0]
 
+    main_guard = None
+    if world > 1:
+        # a rank that never comes back from a collective would leave the driver with nothing at all: after --main-timeout
+        # rank 0 says so in the one line and every rank leaves
+        import threading
+
+        def stuck():
+            if rank == 0:
+                line = json.dumps({"metric": "pairwise_interactions_per_sec", "value": None, "unit": "interactions/s", "n_gpus": world,
+                                   "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                                   "error": f"no result within {args.main_timeout:.0f} s (a rank stuck in the exchange?)"})
+                os.write(json_fd if json_fd is not None else 1, (line + "\n").encode())
+            os._exit(3)
+
+        main_guard = threading.Timer(args.main_timeout, stuck)
+        main_guard.daemon = True
+        main_guard.start()
     elapsed, stats, n_after = run(nb, args, args.workload, args.tree, ics, box, st, rank, world, local_rank, dist, ident_fn)
 
     if dist is not None:
@@ -344,6 +362,8 @@ def main():
         interactions, kernel_ms, launches, visits = float(stats.interactions), stats.force_kernel_ms, float(stats.force_launches), float(stats.node_visits)
         k_inter = float(stats.force_kernel_interactions)
 
+    if main_guard is not None:
+        main_guard.cancel()
     result = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
