@@ -807,6 +807,7 @@ extern "C" int nbody_bh_walk_debug = 0;    // 1: per-wave start/end stamps (tool
 extern "C" int nbody_bh_read_stamps(unsigned long long* out, int n_waves) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbody::nbody_bh_stamps), sizeof(unsigned long long) * 3 * n_waves) == hipSuccess ? 0 : -1;
 }
+extern "C" int nbody_bh_reduce_split = 1;  // 1: four waves per 64 bodies in the plane reduction when there are >= 8 segments
 extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group: 0 = automatic
 extern "C" int nbody_bh_walk_order = 1;    // 1: a group's segments are dispatched nearest-first (heaviest first), 0: in index order
 extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative (scalar loads), 2 = two lanes per body, 3 = hot records in LDS, 4 = wave-cooperative over a window of records, 5 = cooperative block walk (level-order copy)
@@ -840,6 +841,44 @@ __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ pl
         p.x += (v.x * 0.5f) * dt;       // shared.rs:146
         p.y += (v.y * 0.5f) * dt;
         p.z += (v.z * 0.5f) * dt;
+        vel[b] = v;
+        pos[b] = p;
+    }
+}
+
+// The same with Q waves per 64 bodies: wave q adds the planes of the segments [q n_seg / Q, (q + 1) n_seg / Q) and wave 0
+// adds the Q partial sums -- another association than the plain form's, fixed all the same (deterministic).  One thread
+// per body is 256 workgroups at N = 65 536, one per CU, each walking 16 planes in a row: 11 us of mostly latency.
+template <bool KICK, int Q>
+__global__ __launch_bounds__(64 * Q) void k_bh_reduce_split(const float4* __restrict__ planes, int n_seg, size_t plane_stride,
+                                                            const int* __restrict__ order, int n_order, float4* __restrict__ acc,
+                                                            float4* __restrict__ pos, float4* __restrict__ vel, float dt,
+                                                            int* __restrict__ poison, const int* __restrict__ n_order_dev) {
+    __shared__ float part[Q][3][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    if (poison && *poison) return;
+    if (KICK && poison && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(poison + 1, 1);   // a step of an unsynchronised run is complete
+    if (n_order_dev) n_order = min(n_order, *n_order_dev);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (t < n_order) {
+        const int k0 = n_seg * q / Q, k1 = n_seg * (q + 1) / Q;
+        for (int k = k0; k < k1; ++k) {
+            const float4 v = planes[size_t(k) * plane_stride + t];
+            sx += v.x; sy += v.y; sz += v.z;
+        }
+    }
+    part[q][0][lane] = sx; part[q][1][lane] = sy; part[q][2][lane] = sz;
+    __syncthreads();
+    if (q != 0 || t >= n_order) return;
+    sx = part[0][0][lane]; sy = part[0][1][lane]; sz = part[0][2][lane];
+    for (int w = 1; w < Q; ++w) { sx += part[w][0][lane]; sy += part[w][1][lane]; sz += part[w][2][lane]; }
+    const int b = order[t];
+    acc[b] = make_float4(sx, sy, sz, 0.f);
+    if (KICK) {
+        float4 p = pos[b], v = vel[b];
+        v.x += sx * dt; v.y += sy * dt; v.z += sz * dt;                                       // shared.rs:144
+        p.x += (v.x * 0.5f) * dt; p.y += (v.y * 0.5f) * dt; p.z += (v.z * 0.5f) * dt;         // shared.rs:146
         vel[b] = v;
         pos[b] = p;
     }
@@ -915,7 +954,17 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
 #undef WALK
     }
     }
-    if (t.n_split > 1) {
+    if (t.n_split >= 8 && fast_math && nbody_bh_reduce_split) {   // (strict math never splits; the plain form keeps the single walk's order)
+        const dim3 rg((t.n_order + 63) / 64);
+        if (kick_dt) {
+            hipLaunchKernelGGL((k_bh_reduce_split<true, 4>), rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order, t.n_order,
+                               sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.poison, t.n_order_dev);
+            if (kicked) *kicked = 1;
+        } else {
+            hipLaunchKernelGGL((k_bh_reduce_split<false, 4>), rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order, t.n_order,
+                               sh.acc, sh.own_pos(), sh.vel, 0.f, sh.poison, t.n_order_dev);
+        }
+    } else if (t.n_split > 1) {
         const dim3 rg((t.n_order + 255) / 256);
         if (kick_dt) {
             hipLaunchKernelGGL(k_bh_reduce<true>, rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order,
