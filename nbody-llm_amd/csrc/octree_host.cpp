@@ -411,7 +411,9 @@ void build_octree(const T* pos4, int n_seg, int seg_cap, const int* count, const
         // as separate tasks beside the chunk work.  Everything smaller becomes a subtree task.
         // Depth alone is a poor cut: a Plummer sphere in a wide box keeps most bodies in 8 cells
         // per level for several levels.
-        struct Big { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; int self; int pn; };  // pn: bodies in the parent cell
+        struct Big { Item* src; Item* tmp; uint8_t* code; int n; Box box; int depth; int self; int pn; int fold_from; };  // pn: bodies in the parent cell
+        // fold_from >= 0: the cell holds exactly the bodies of that ancestor, in the same order (a cluster much smaller than
+        // the box sits in one child per level for several levels): same sums, same bits -- copied, and nothing was moved
         struct TNode { NodeA a{}; NodeB b{}; int child[8]; int task = -1; int depth = 0; };
         std::vector<TNode> tn;
         auto new_tnode = [&](const Box& bx, int hot, int depth) { TNode t; t.b = NodeB{bx.w * bx.w, 0, hot, -1}; t.depth = depth; for (int& c : t.child) c = -1; tn.push_back(t); return int(tn.size()) - 1; };
@@ -432,7 +434,7 @@ void build_octree(const T* pos4, int n_seg, int seg_cap, const int* count, const
         pool.post_background(fold_root);
         pool.run(n_thr, [&](int t) { const size_t c = (n + n_thr - 1) / n_thr; fill(std::min(n, size_t(t) * c), std::min(n, size_t(t + 1) * c)); });
         lap("fill");
-        std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root, int(n), 0), int(n)}};
+        std::vector<Big> level{Big{A, B, C, int(n), root, 0, new_tnode(root, int(n), 0), int(n), -1}};
         struct Piece { int node; int k0, k1; };
         while (!level.empty()) {
             std::vector<Piece> pieces;
@@ -444,6 +446,7 @@ void build_octree(const T* pos4, int n_seg, int seg_cap, const int* count, const
                 if (t < NB) {  // the node's fold (handed out first: they are the long tasks of the run)
                     const Big& g = level[t];
                     if (g.depth == 0) return;  // the root's runs in the background
+                    if (g.fold_from >= 0) { tn[g.self].a = tn[g.fold_from].a; return; }
                     T mass = 0, sx = 0, sy = 0, sz = 0;
                     for (int k = 0; k < g.n; ++k) { const Item& it = g.src[k]; mass += it.m; sx += it.x * it.m; sy += it.y * it.m; sz += it.z * it.m; }
                     tn[g.self].a = NodeA{sx / mass, sy / mass, sz / mass, mass};
@@ -467,9 +470,17 @@ void build_octree(const T* pos4, int n_seg, int seg_cap, const int* count, const
             for (int b = 0; b < NB; ++b) { int run = 0; for (int o = 0; o < 8; ++o) { nstart[b][o] = run; run += ntot[b][o]; } }
             { std::vector<std::array<int, 8>> run = nstart;
               for (int t = 0; t < NP; ++t) for (int o = 0; o < 8; ++o) { poff[t][o] = run[pieces[t].node][o]; run[pieces[t].node][o] += pcnt[t][o]; } }
-            pool.run(NP, [&](int t) {
+            // a node all of whose bodies went to ONE child: nothing to move, the child works on the same arrays
+            std::vector<char> same(NB, 0);
+            bool any_move = false;
+            for (int b = 0; b < NB; ++b) {
+                for (int o = 0; o < 8; ++o) if (ntot[b][o] == level[b].n) same[b] = 1;
+                if (!same[b]) any_move = true;
+            }
+            if (any_move) pool.run(NP, [&](int t) {
                 const Piece& pc = pieces[t];
                 const Big& g = level[pc.node];
+                if (same[pc.node]) return;
                 int o8[8];
                 for (int o = 0; o < 8; ++o) o8[o] = poff[t][o];
                 for (int k = pc.k0; k < pc.k1; ++k) g.tmp[o8[g.code[k]]++] = g.src[k];
@@ -483,14 +494,16 @@ void build_octree(const T* pos4, int n_seg, int seg_cap, const int* count, const
                     const Box cb = g.box.child(o);
                     const int id = new_tnode(cb, g.pn, g.depth + 1);  // the child's grandparent is g's parent
                     tn[g.self].child[o] = id;
-                    Item* csrc = g.tmp + nstart[b][o];
-                    Item* ctmp = g.src + nstart[b][o];
+                    Item* csrc = (same[b] ? g.src : g.tmp) + nstart[b][o];
+                    Item* ctmp = (same[b] ? g.tmp : g.src) + nstart[b][o];
                     uint8_t* ccode = g.code + nstart[b][o];
                     if (cn == 1) {
                         tn[id].a = NodeA{csrc[0].x, csrc[0].y, csrc[0].z, csrc[0].m};
                         tn[id].b.body = csrc[0].id;
                     } else if (cn > big && g.depth + 1 < 24) {
-                        next.push_back(Big{csrc, ctmp, ccode, cn, cb, g.depth + 1, id, g.n});
+                        // (the root's own fold runs in the background and lands after the loop: its only child folds itself)
+                        const int from = (same[b] && g.depth > 0) ? (g.fold_from >= 0 ? g.fold_from : g.self) : -1;
+                        next.push_back(Big{csrc, ctmp, ccode, cn, cb, g.depth + 1, id, g.n, from});
                     } else {
                         tn[id].task = int(tasks.size());
                         tasks.push_back(Task{csrc, ctmp, ccode, cn, cb, g.depth + 1, nullptr, g.n, g.pn});
