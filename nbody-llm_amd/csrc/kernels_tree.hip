@@ -104,29 +104,50 @@ __device__ __forceinline__ int common_levels2(const unsigned long long* __restri
     return c < kLevels ? c : kLevels + common_levels(keys2[a], keys2[b]);
 }
 
-// After the sort: the first body of every group of equal keys gives the group its second keys (levels 21..41) and puts
-// it in their order (insertion sort, stable: the radix sort left the ids ascending).  Groups are pairs in practice; one
-// of more than nbody_tree_max_tie bodies (64) is reported as too deep rather than sorted by a single thread.
+// The radix sort covers the top 48 bits of the keys only (16 levels: 6 passes of 8 bits instead of 8 -- two launches and
+// a quarter of the histogram less, 12-16 us of a ~100 us build); what it leaves is finished here.  The first body of every
+// group of equal TOP bits (bodies that share 16 levels: a handful here and there) sorts the group by the full key
+// (insertion sort; the radix sort is stable, so equal keys keep ascending ids), and inside it every run of equal FULL
+// keys gets its second keys (levels 21..41) and is put in their order.  Groups are pairs in practice; a group of more
+// than kMaxLowGroup bodies, or a run of more than nbody_tree_max_tie (64) equal keys, is reported as too deep rather than
+// sorted by a single thread.
+constexpr int kSortLowBits = 15;    // key bits the radix sort leaves to k_tree_ties (levels 16..20)
+constexpr int kMaxLowGroup = 256;
 template <class P4, class Real>
 __global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, const int* __restrict__ count, Real cx0, Real cy0,
-                                                   Real cz0, Real width, const unsigned long long* __restrict__ keys,
+                                                   Real cz0, Real width, unsigned long long* __restrict__ keys,
                                                    unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
                                                    int kMaxTie) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
     if (j + 1 >= n) return;
-    const unsigned long long key = keys[j];
-    if (keys[j + 1] != key || (j > 0 && keys[j - 1] == key)) return;
+    const unsigned long long top = keys[j] >> kSortLowBits;
+    if ((keys[j + 1] >> kSortLowBits) != top || (j > 0 && (keys[j - 1] >> kSortLowBits) == top)) return;
     int e = j + 2;
-    while (e < n && e - j <= kMaxTie && keys[e] == key) ++e;
-    if (e - j > kMaxTie) { atomicOr(flags, 1); return; }
-    for (int q = j; q < e; ++q) keys2[q] = orthant_key(pos[ids[q]], cx0, cy0, cz0, width, kLevels);
-    for (int q = j + 1; q < e; ++q) {
-        const unsigned long long k2 = keys2[q];
+    while (e < n && e - j <= kMaxLowGroup && (keys[e] >> kSortLowBits) == top) ++e;
+    if (e - j > kMaxLowGroup) { atomicOr(flags, 1); return; }
+    for (int q = j + 1; q < e; ++q) {           // by the full key
+        const unsigned long long k = keys[q];
         const int id = ids[q];
         int r = q - 1;
-        while (r >= j && keys2[r] > k2) { keys2[r + 1] = keys2[r]; ids[r + 1] = ids[r]; --r; }
-        keys2[r + 1] = k2; ids[r + 1] = id;
+        while (r >= j && keys[r] > k) { keys[r + 1] = keys[r]; ids[r + 1] = ids[r]; --r; }
+        keys[r + 1] = k; ids[r + 1] = id;
+    }
+    for (int a = j; a + 1 < e;) {               // runs of equal full keys: by the second key
+        int z = a + 1;
+        while (z < e && keys[z] == keys[a]) ++z;
+        if (z - a > 1) {
+            if (z - a > kMaxTie) { atomicOr(flags, 1); return; }
+            for (int q = a; q < z; ++q) keys2[q] = orthant_key(pos[ids[q]], cx0, cy0, cz0, width, kLevels);
+            for (int q = a + 1; q < z; ++q) {
+                const unsigned long long k2 = keys2[q];
+                const int id = ids[q];
+                int r = q - 1;
+                while (r >= a && keys2[r] > k2) { keys2[r + 1] = keys2[r]; ids[r + 1] = ids[r]; --r; }
+                keys2[r + 1] = k2; ids[r + 1] = id;
+            }
+        }
+        a = z;
     }
 }
 
@@ -434,7 +455,7 @@ size_t sum4_scan_tmp_bytes(size_t n_cap) { return ((n_cap + kScanTile - 1) / kSc
 size_t scratch_bytes(size_t n_cap) {
     size_t sort_bytes = 0, scan_i = 0;
     unsigned long long* k = nullptr; int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 63, 0);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 64, 0);
     (void)rocprim::exclusive_scan(nullptr, scan_i, v, v, 0, n_cap, rocprim::plus<int>(), 0);
     return (std::max(sort_bytes, std::max(scan_i, sum4_scan_tmp_bytes(n_cap))) + 255) / 256 * 256;
 }
@@ -524,7 +545,9 @@ int sort_keys_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, c
     hipLaunchKernelGGL((k_tree_keys<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, n, center[0], center[1], center[2], width,
                        L.keys_in, L.ids_in, out_info);
     size_t tb = L.tmp_bytes;
-    if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), 0, 64, s) != hipSuccess) return -1;
+    // (bits [15, 63): the unused tail's keys are all ones and stay behind every real body -- the sort is stable and the
+    // tail comes last in the input; k_tree_ties finishes the low bits)
+    if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), kSortLowBits, 63, s) != hipSuccess) return -1;
     hipLaunchKernelGGL((k_tree_ties<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width,
                        L.keys, L.keys2, L.ids, out_info + 1, std::max(1, nbody_tree_max_tie));
     return 0;

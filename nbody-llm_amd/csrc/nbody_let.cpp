@@ -457,7 +457,7 @@ static int account(NbodyHandle* h, State& s) {
     s.st.nodes_sent += sent;
     s.st.nodes_local += uint64_t(std::max(0, s.h_pin[40]));
     s.st.nodes_global += uint64_t(std::max(0, s.h_pin[16 + s.G]));
-    h->stats.tree_nodes = uint64_t(std::max(0, s.h_pin[16 + s.G]));
+    h->stats.tree_nodes = uint64_t(std::max(1, s.h_pin[16 + s.G]));   // (an empty world: the reference's empty root, barnes_hut.rs:145)
     h->n_local = size_t(std::max(0, s.h_pin[42]));   // the live own count (bodies in the local build)
     h->seg_count_host[0] = int(h->n_local);
     h->count_dirty = false;
