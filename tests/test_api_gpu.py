@@ -100,3 +100,28 @@ def test_many_handles_share_a_device(gpu, orc):
             ref = orc.bf_step_by(ref, sd, BOX[0], BOX[1], sd["dt"])
         assert np.array_equal(s.get_points()["position"], ref["position"])
         s.close()
+
+
+@pytest.mark.parametrize("method", ["bf", "bh"])
+def test_clone_of_a_handle_with_a_live_communicator(gpu, method):
+    """`Clone` (shared.rs:80): the twin of a handle whose RCCL communicator is up (a world of one here) has the state
+    but not the communicator, steps on its own, and leaves the original and its communicator usable."""
+    nb = gpu
+    ics = nb.plummer(3000, seed=81)
+    m = nb.BRUTE_FORCE if method == "bf" else nb.BARNES_HUT
+    with nb.Simulation(ics, (0, 0, 0), 64.0, method=m, math_mode=nb.FAST) as sim:
+        sim.settings = nb.Settings(1.0, 0.01, 1e-3, 0.25)
+        sim.comm_init(nb.comm_unique_id())
+        sim.steps(3)
+        twin = sim.clone()
+        try:
+            sim.steps(2)
+            twin.steps(2)
+            a, b = sim.get_points(), twin.get_points()
+            assert sim.elapsed() == twin.elapsed()
+            for f in ("position", "velocity", "acceleration", "mass"):
+                assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+            sim.steps(1)                      # the original's communicator survived the clone
+            assert len(sim) == len(twin) == 3000
+        finally:
+            twin.close()
