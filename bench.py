@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--spatial-timeout", type=float, default=300.0, help="seconds before the configs[3]/configs[4] objects are given up")
     ap.add_argument("--large-n", type=int, default=1 << 20, help="N > 1 GPUs: bodies of the configs[3] object (0: leave it out)")
     ap.add_argument("--large-steps", type=int, default=5)
+    ap.add_argument("--driver-n", type=int, default=100000, help="one GPU: disc bodies of the reference driver's workload (0: leave it out)")
     ap.add_argument("--main-timeout", type=float, default=600.0, help="N > 1 GPUs: seconds before the metric's own run is declared stuck")
     ap.add_argument("--seed", type=int, default=20250523)
     return ap.parse_args()
@@ -482,6 +483,36 @@ def main():
                     "parity": "fast math, device build: node counts equal the single-GPU tree's, accelerations to rounding (tests/test_spatial_gpu.py, "
                               "tests/test_large_gpu.py at this size, one-GPU emulation of the ranks)",
                 }
+
+    # the reference's own benchmark (src/main.rs:52-129 through its Simulation trait): the 100 000-body disc, Barnes-Hut,
+    # theta2 = 1, dt = 3e-2, g_soft = 0.02 -- the only workload with published numbers (its authors' perf CSVs,
+    # other hardware, f64, 32 CPU threads: context, not a vs_baseline)
+    if args.workload == "bf" and world == 1 and not args.no_bh and args.driver_n > 0:
+        ref = {}
+        rbox = ((0.0, 0.0, 0.0), 10.0)
+        rst = dict(g=1.0, g_soft=0.02, dt=3e-2, theta2=1.0)
+        for name, f64, tree, mm, k in (("f32_fast_device_tree", False, nb.TREE_DEVICE, nb.FAST, 300), ("f32_strict_host_tree", False, nb.TREE_HOST, nb.STRICT, 60),
+                                       ("f64_host_tree", True, nb.TREE_HOST, nb.STRICT, 40), ("f64_device_tree", True, nb.TREE_DEVICE, nb.STRICT, 120)):
+            d = nb.disc(args.driver_n, seed=1, f64=f64)
+            with nb.Simulation(d, *rbox, method=nb.BARNES_HUT, math_mode=mm, tree_build=tree, f64=f64) as sim:
+                sim.settings = nb.Settings(**rst)
+                sim.init()
+                sim.steps(5)
+                sim.sync()
+                t0 = time.perf_counter()
+                sim.steps(k)
+                sim.sync()
+                ref[name] = {"steps_per_sec": k / (time.perf_counter() - t0), "steps": k, "bodies_left": len(sim)}
+        if rank == 0:
+            result["reference_driver"] = {
+                "workload": f"src/main.rs: 1 star + {args.driver_n} disc bodies, box 10, Barnes-Hut theta2 = 1.0, dt = 3e-2, g_soft = 0.02 "
+                            "(what `nbody_cli -t T -n N` and the reference's perf_benchmark.py run)",
+                **ref,
+                "published_cpu": {"steps_per_sec": 8.1, "what": "the reference on a 32-thread AMD Zen host, f64, N = 100 000 (BASELINE.md, "
+                                                                "combined_nbody_man_opt.csv:2881): other hardware, context only"},
+                "parity": "f64_host_tree and f32_strict_host_tree: bit-exact vs the oracle (tests/test_f64_gpu.py::test_reference_driver_configuration_in_f64, "
+                          "tests/test_bh_gpu.py); the device-tree entries: same cells, node counts within 1e-3 (f32) / 1e-6 (f64)",
+            }
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
