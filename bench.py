@@ -98,7 +98,7 @@ def cpu_baseline(orc, ics, settings, box, workload):
     """The oracle (a port of the reference's CPU path) on this box's host cores, bounded to ~10-30 s."""
     center, width = box
     n = len(ics)
-    flags = "g++ -O3 -ffp-contract=off, no -march=native (built off-box; oracle/Makefile)"
+    flags = orc.use_native()
     if workload == "bf":
         # the reference loop is serial (brute_force.rs:70-81): one thread, one pass over all bodies
         # (~9 s at N = 65 536); larger N are cut to 65 536 bodies

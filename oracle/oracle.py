@@ -22,6 +22,23 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+BUILD_FLAGS = "g++ -O3 -ffp-contract=off, no -march=native (built off-box; oracle/Makefile)"
+
+
+def use_native() -> str:
+    """bench.py's cpu_baseline leg: the oracle rebuilt for THIS machine (-march=native, same source, same
+    -ffp-contract=off: same results) if a compiler is here and the library is not loaded yet.  Returns the flags in use."""
+    global LIB_PATH, BUILD_FLAGS
+    if _lib is None:
+        native = os.path.join(_HERE, "libnbody_oracle_native.so")
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            C.CDLL(native)   # (loads on this CPU?)
+            LIB_PATH = native
+            BUILD_FLAGS = "g++ -O3 -march=native -ffp-contract=off, built on the box the number comes from (oracle/Makefile `native`)"
+        except Exception:  # noqa: BLE001 -- no compiler on the box: the portable build
+            pass
+    return BUILD_FLAGS
 
 
 def lib():
