@@ -37,5 +37,17 @@ for cnt in sorted(set(per_simd.values())):
     ls = [max(x[0] for x in v) for k, v in bysimd.items() if len(v) == cnt]
     cs = [np.mean([x[1] for x in v]) for k, v in bysimd.items() if len(v) == cnt]
     print(f"SIMDs with {cnt} waves: {len(ls)}; last wave ends at median {np.median(ls):.0f} us; mean cycles/step per wave {np.mean(cs):.0f}")
+# is the spread systematic?  lifetimes by XCD and by shader engine, and the spread inside one CU
+for name, grp in (("XCD", [int(x) for x in xcc]), ("XCD,SE", [(int(x), int(e)) for x, e in zip(xcc, se)])):
+    by = collections.defaultdict(list)
+    for g, l in zip(grp, life):
+        by[g].append(l)
+    print(f"lifetime by {name}:", "  ".join(f"{g}: med {np.median(v):.0f} max {np.max(v):.0f}" for g, v in sorted(by.items())))
+bycu = collections.defaultdict(list)
+for k, l in zip(key_cu, life):
+    bycu[k].append(l)
+spread_in_cu = [max(v) - min(v) for v in bycu.values()]
+cu_max = [max(v) for v in bycu.values()]
+print(f"inside a CU: lifetime spread median {np.median(spread_in_cu):.0f} us; across CUs: slowest wave of a CU from {min(cu_max):.0f} to {max(cu_max):.0f} us (median {np.median(cu_max):.0f})")
 print("first 16 waves (one workgroup): simd ids", [int(x) for x in simd[:16]], "cu", [int(x) for x in cu[:16]])
 dbg.value = 0
