@@ -1005,7 +1005,9 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (spatial) {   // a spatial handle holds its own bodies only (no gathered positions): one segment, with room for immigrants
         sh.n_seg = 1;
         sh.my_seg = 0;
-        if (cfg->world_size > 1) sh.seg_cap = int(std::min<uint64_t>(cfg->capacity, 2 * uint64_t(sh.seg_cap) + 64));
+        // (four times the even share: the bounds equalise the ranks' WORK, and a rank of cheap bodies -- a sparse halo --
+        // owns more than the average; NBODY_ERR_CAPACITY beyond that)
+        if (cfg->world_size > 1) sh.seg_cap = int(std::min<uint64_t>(cfg->capacity, 4 * uint64_t(sh.seg_cap) + 64));
     }
     const size_t cap = size_t(sh.seg_cap);
     CREATE_TRY(hipMalloc(&sh.pos_all, size_t(sh.n_seg) * cap * sizeof(float4)));
