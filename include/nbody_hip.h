@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 3
+#define NBODY_ABI_VERSION 4
 
 typedef struct NbodyHandle NbodyHandle;
 
@@ -187,9 +187,19 @@ const char* nbody_last_error(const NbodyHandle* h); /* h may be NULL: last creat
 /* ---- multi-GPU (no reference counterpart) ------------------------ */
 #define NBODY_COMM_ID_BYTES 128
 /* rank 0 calls nbody_comm_unique_id and ships the bytes to the other ranks out of band; every
- * rank then calls nbody_comm_init on its handle (collective). */
+ * rank then calls nbody_comm_init on its handle (collective).  The id names the transport of the exchanges:
+ *   nbody_comm_unique_id  RCCL (one process per GPU, xGMI) -- or, with NBODY_TRANSPORT=ipc in the environment, the same
+ *                         as nbody_comm_local_id;
+ *   nbody_comm_local_id   ranks that share ONE device (processes, or threads of one process, on the same host): payloads
+ *                         staged through hipIpc-shared windows, flags in host shared memory (csrc/transport_ipc.hip).
+ *                         RCCL refuses two ranks on one device; this is how the multi-rank step runs on a one-GPU box.
+ * nbody_comm_init also checks that every rank was created alike (ABI version, method, arithmetic, sharding, capacity,
+ * exchange scheme): a rank that differs gets NBODY_ERR_COMM there instead of a hang in the first exchange. */
 int nbody_comm_unique_id(void* id_bytes);
+int nbody_comm_local_id(void* id_bytes);
 int nbody_comm_init(NbodyHandle* h, const void* id_bytes);
+/* "rccl", "ipc" or "none" */
+int nbody_comm_transport(const NbodyHandle* h, char* out, size_t cap);
 /* first global index and length of this rank's block at upload time */
 int nbody_local_range(const NbodyHandle* h, size_t* first, size_t* count);
 /* NBODY_SHARD_SPATIAL: a rank's bodies are not an index block (and change as bodies migrate).  This gives, in the

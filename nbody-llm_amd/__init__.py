@@ -69,6 +69,7 @@ DECLARED_SYMBOLS = [
     "nbody_tree_export_f64", "nbody_ic_plummer_f64", "nbody_ic_disc_f64",
     "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
     "nbody_debug_let_bounds", "nbody_debug_let_set_balance",
+    "nbody_comm_local_id", "nbody_comm_transport",
 ]
 
 
@@ -131,6 +132,8 @@ _sig("nbody_tree_export", _i, _H, C.c_void_p, C.c_void_p, C.c_void_p, _sz, C.POI
 _sig("nbody_last_error", C.c_char_p, _H)
 _sig("nbody_comm_unique_id", _i, C.c_void_p)
 _sig("nbody_comm_init", _i, _H, C.c_void_p)
+_sig("nbody_comm_local_id", _i, C.c_void_p)
+_sig("nbody_comm_transport", _i, _H, C.c_char_p, _sz)
 _sig("nbody_local_range", _i, _H, C.POINTER(_sz), C.POINTER(_sz))
 _sig("nbody_ic_plummer", _i, C.c_void_p, _sz, _sz, C.c_uint64)
 _sig("nbody_ic_disc", _i, C.c_void_p, _sz, _sz, C.c_uint64)
@@ -436,6 +439,11 @@ class Simulation:
         buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
         self._check(lib.nbody_comm_init(self._h, buf))
 
+    def comm_transport(self) -> str:
+        buf = C.create_string_buffer(16)
+        self._check(lib.nbody_comm_transport(self._h, buf, 16))
+        return buf.value.decode()
+
 
 def sharded_step(sims: list, dt: float | None = None):
     """One step of a world of len(sims) shards living in this process (test harness: what the RCCL
@@ -500,8 +508,18 @@ def host_cross_plan(rank: int, world: int, seg_cap: int, n_own: int) -> dict:
 
 
 def comm_unique_id() -> bytes:
+    """Id of an RCCL communicator (NBODY_TRANSPORT=ipc in the environment: of the one-device transport)."""
     buf = C.create_string_buffer(COMM_ID_BYTES)
     rc = lib.nbody_comm_unique_id(buf)
+    if rc:
+        raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
+    return buf.raw
+
+
+def comm_local_id() -> bytes:
+    """Id of the one-device transport: ranks (processes or threads) that share a GPU."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.nbody_comm_local_id(buf)
     if rc:
         raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
     return buf.raw

@@ -49,11 +49,10 @@ int fail(NbodyHandle* h, int code, const std::string& msg) {
             return fail(h, NBODY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-#define NCCL_TRY(h, expr)                                                                             \
+#define TP_TRY(h, expr)                                                                               \
     do {                                                                                              \
-        ncclResult_t r_ = (expr);                                                                     \
-        if (r_ != ncclSuccess)                                                                        \
-            return fail(h, NBODY_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));       \
+        int r_ = (expr);                                                                              \
+        if (r_ != NBODY_OK) return fail(h, r_, std::string(#expr) + ": " + (h)->tp->error());         \
     } while (0)
 
 void* pinned_alloc(size_t n) {
@@ -119,10 +118,10 @@ int exchange_begin(NbodyHandle* h) {
     // comm stream: after the drift/compaction of this step, beside whatever the compute stream does next
     HIP_TRY(h, hipEventRecord(h->ev_drifted, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_drifted, 0));
-    NCCL_TRY(h, ncclGroupStart());
-    NCCL_TRY(h, ncclAllGather(h->sh.own_pos(), h->sh.pos_all, size_t(h->sh.seg_cap) * 4, ncclFloat, h->comm, h->comm_stream));
-    NCCL_TRY(h, ncclAllGather(h->sh.own_count(), h->sh.seg_count, 1, ncclInt32, h->comm, h->comm_stream));
-    NCCL_TRY(h, ncclGroupEnd());
+    TP_TRY(h, h->tp->group_begin());
+    TP_TRY(h, h->tp->all_gather(h->sh.pos_all, size_t(h->sh.seg_cap) * sizeof(float4), h->comm_stream));
+    TP_TRY(h, h->tp->all_gather(h->sh.seg_count, sizeof(int), h->comm_stream));
+    TP_TRY(h, h->tp->group_end());
     HIP_TRY(h, hipEventRecord(h->ev_gathered, h->comm_stream));
     h->exchange_in_flight = true;
     return NBODY_OK;
@@ -134,6 +133,13 @@ int exchange_wait(NbodyHandle* h) {
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_gathered, 0));
     h->exchange_in_flight = false;
     return NBODY_OK;
+}
+
+// anything the transport noticed behind the host's back (a device-side wait that ran out of time, a peer that gave up)
+int comm_check(NbodyHandle* h) {
+    if (!h->tp) return NBODY_OK;
+    int rc = h->tp->check();
+    return rc ? fail(h, rc, h->tp->error()) : NBODY_OK;
 }
 
 struct ForceTimer {  // HIP events around a force-kernel launch, on the launch stream
@@ -800,15 +806,15 @@ int partials_begin(NbodyHandle* h) {
     if (!h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
     const nbody::CrossPlan& c = h->cross;
     const size_t S = h->sym_plan.plane_stride;
-    const size_t count = size_t(h->sh.seg_cap) * 4;
+    const size_t bytes = size_t(h->sh.seg_cap) * sizeof(float4);
     HIP_TRY(h, hipEventRecord(h->ev_partials_ready, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_partials_ready, 0));
-    NCCL_TRY(h, ncclGroupStart());
+    TP_TRY(h, h->tp->group_begin());
     for (int i = 0; i < c.parts.n; ++i)
-        NCCL_TRY(h, ncclSend(h->d_send + size_t(i) * S, count, ncclFloat, c.parts.seg[i], h->comm, h->comm_stream));
+        TP_TRY(h, h->tp->send(h->d_send + size_t(i) * S, bytes, c.parts.seg[i], h->comm_stream));
     for (int i = 0; i < c.n_recv; ++i)
-        NCCL_TRY(h, ncclRecv(h->d_planes + size_t(h->recv_plane0 + i) * S, count, ncclFloat, c.recv_from[i], h->comm, h->comm_stream));
-    NCCL_TRY(h, ncclGroupEnd());
+        TP_TRY(h, h->tp->recv(h->d_planes + size_t(h->recv_plane0 + i) * S, bytes, c.recv_from[i], h->comm_stream));
+    TP_TRY(h, h->tp->group_end());
     HIP_TRY(h, hipEventRecord(h->ev_partials_done, h->comm_stream));
     h->partials_in_flight = true;
     return NBODY_OK;
@@ -911,7 +917,7 @@ void free_all(NbodyHandle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    if (h->comm) (void)ncclCommDestroy(h->comm);
+    h->tp.reset();   // (leaves the world: the ipc transport waits, bounded, until its peers are done with its window)
     if (h->ev_drifted) (void)hipEventDestroy(h->ev_drifted);
     if (h->ev_gathered) (void)hipEventDestroy(h->ev_gathered);
     if (h->ev_partials_ready) (void)hipEventDestroy(h->ev_partials_ready);
@@ -1191,6 +1197,8 @@ int nbody_download(NbodyHandle* h, void* aos, size_t cap, size_t stride, size_t*
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_aos, h->d_aos, n * 40, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    rc = comm_check(h);   // (bodies of a run whose exchange broke down are not handed out as results)
+    if (rc) return rc;
     char* dst = static_cast<char*>(aos);
     for (size_t k = 0; k < n; ++k) std::memcpy(dst + k * stride, h->h_aos + 10 * k, 40);
     return NBODY_OK;
@@ -1409,7 +1417,7 @@ int nbody_sync(NbodyHandle* h) {
     rc = resolve_async(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return NBODY_OK;
+    return comm_check(h);
 }
 
 int nbody_set_profiling(NbodyHandle* h, int on) {
@@ -1540,24 +1548,44 @@ int nbody_tree_export_f64(NbodyHandle* h, double* com_mass, double* width, int32
 
 int nbody_comm_unique_id(void* id_bytes) {
     if (!id_bytes) return NBODY_ERR_INVALID;
-    static_assert(sizeof(ncclUniqueId) <= NBODY_COMM_ID_BYTES, "ncclUniqueId larger than NBODY_COMM_ID_BYTES");
-    ncclUniqueId id;
-    ncclResult_t r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) return fail(nullptr, NBODY_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
-    std::memset(id_bytes, 0, NBODY_COMM_ID_BYTES);
-    std::memcpy(id_bytes, &id, sizeof(id));
-    return NBODY_OK;
+    // NBODY_TRANSPORT=ipc: ranks that share one device (a one-GPU box rehearsing the multi-rank step); default: RCCL
+    const char* v = std::getenv("NBODY_TRANSPORT");
+    std::string err;
+    int rc = nbody::transport_make_id((v && std::strcmp(v, "ipc") == 0) ? nbody::kTransportIpc : nbody::kTransportRccl, id_bytes, &err);
+    return rc ? fail(nullptr, rc, err) : NBODY_OK;
 }
+
+int nbody_comm_local_id(void* id_bytes) {
+    if (!id_bytes) return NBODY_ERR_INVALID;
+    std::string err;
+    int rc = nbody::transport_make_id(nbody::kTransportIpc, id_bytes, &err);
+    return rc ? fail(nullptr, rc, err) : NBODY_OK;
+}
+
+// what every rank of a world must agree on: a rank that chose another exchange scheme than its peers would neither send
+// nor expect what the others exchange with it (a hang in RCCL), so disagreement is an error at nbody_comm_init
+struct Agreement {
+    int32_t abi, method, math_mode, leaf_mode, tree_build, dtype, shard_mode, world, seg_cap;
+    int32_t cross_sym, sym_packed, bf_variant, walk_variant, walk_split;
+    uint64_t capacity;
+};
+static const char* const kAgreementFields[] = {"ABI version", "method", "math_mode", "leaf_mode", "tree_build", "dtype", "shard_mode", "world_size",
+                                               "shard capacity", "NBODY_CROSS_SYM", "NBODY_SYM_PACKED", "NBODY_BF_VARIANT", "NBODY_BH_VARIANT",
+                                               "NBODY_BH_SPLIT"};
 
 int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
     if (!h || !id_bytes) return NBODY_ERR_INVALID;
     if (h->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     int rc = use_device(h);
     if (rc) return rc;
-    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; h->comm_ready = false; }
-    ncclUniqueId id;
-    std::memcpy(&id, id_bytes, sizeof(id));
-    NCCL_TRY(h, ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+    h->comm_ready = false;
+    h->tp.reset();
+    {
+        std::string err;
+        int code = NBODY_ERR_COMM;
+        h->tp.reset(nbody::transport_create(id_bytes, h->cfg.rank, h->cfg.world_size, h->device, &err, &code));
+        if (!h->tp) return fail(h, code, err);
+    }
     if (!h->comm_stream) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_drifted, hipEventDisableTiming));
@@ -1565,7 +1593,32 @@ int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_partials_ready, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_partials_done, hipEventDisableTiming));
     }
+    Agreement mine{NBODY_ABI_VERSION, h->cfg.method, h->cfg.math_mode, h->cfg.leaf_mode, h->cfg.tree_build, h->cfg.dtype, h->cfg.shard_mode,
+                   h->cfg.world_size, h->sh.seg_cap, nbody_cross_sym, nbody_sym_packed, nbody_bf_fast_variant, nbody_bh_walk_variant,
+                   nbody_bh_walk_split, h->cfg.capacity};
+    std::vector<Agreement> all(size_t(h->cfg.world_size));
+    TP_TRY(h, h->tp->host_all_gather(&mine, all.data(), sizeof(Agreement)));
+    for (int r = 0; r < h->cfg.world_size; ++r) {
+        const int32_t* a = reinterpret_cast<const int32_t*>(&all[size_t(r)]);
+        const int32_t* m = reinterpret_cast<const int32_t*>(&mine);
+        for (size_t f = 0; f < sizeof(kAgreementFields) / sizeof(kAgreementFields[0]); ++f)
+            if (a[f] != m[f]) {
+                h->tp.reset();
+                return fail(h, NBODY_ERR_COMM, std::string("nbody_comm_init: rank ") + std::to_string(r) + " and rank " + std::to_string(h->cfg.rank) + " disagree on " +
+                                                   kAgreementFields[f] + " (" + std::to_string(a[f]) + " vs " + std::to_string(m[f]) + "): every rank of a world must be created alike");
+            }
+        if (all[size_t(r)].capacity != mine.capacity) {
+            h->tp.reset();
+            return fail(h, NBODY_ERR_COMM, "nbody_comm_init: ranks disagree on NbodyConfig.capacity");
+        }
+    }
     h->comm_ready = true;
+    return NBODY_OK;
+}
+
+int nbody_comm_transport(const NbodyHandle* h, char* out, size_t cap) {
+    if (!h || !out || cap == 0) return NBODY_ERR_INVALID;
+    std::snprintf(out, cap, "%s", h->tp ? h->tp->name() : "none");
     return NBODY_OK;
 }
 

@@ -4,8 +4,9 @@
 #include "kernels.h"
 #include "octree_host.h"
 
+#include "transport.h"
+
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <memory>
 #include <string>
@@ -120,8 +121,8 @@ struct NbodyHandle {
     double* d_energy = nullptr;
     size_t energy_blocks = 0;
 
-    // multi-GPU
-    ncclComm_t comm = nullptr;
+    // multi-GPU: what carries the exchanges (RCCL, or the one-device transport of transport_ipc.hip)
+    std::unique_ptr<nbody::Transport> tp;
     bool comm_ready = false;
     hipStream_t comm_stream = nullptr;   // the exchange runs here, beside the own-shard force kernel
     hipEvent_t ev_drifted = nullptr, ev_gathered = nullptr;

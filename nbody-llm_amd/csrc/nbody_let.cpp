@@ -86,11 +86,10 @@ int fail(NbodyHandle* h, int code, const std::string& msg) { h->err = msg; retur
         if (e_ != hipSuccess)                                                                         \
             return fail(h, NBODY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
-#define NCCL_TRY(h, expr)                                                                             \
+#define TP_TRY(h, expr)                                                                               \
     do {                                                                                              \
-        ncclResult_t r_ = (expr);                                                                     \
-        if (r_ != ncclSuccess)                                                                        \
-            return fail(h, NBODY_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));       \
+        int r_ = (expr);                                                                              \
+        if (r_ != NBODY_OK) return fail(h, r_, std::string(#expr) + ": " + (h)->tp->error());         \
     } while (0)
 
 // phase timing: an event at both ends of a phase, on the handle's stream; account() adds the five durations up
@@ -479,64 +478,85 @@ static int account(NbodyHandle* h, State& s) {
     return NBODY_OK;
 }
 
-// ---- production: the exchanges with RCCL
+// Where the variable-size rounds put their messages (host arithmetic shared by sender and receiver: both sides of a
+// pair read the same all-gathered matrix, so the byte counts of a send and of the receive that meets it are the same
+// expression).  m = the G x G count matrix, row r = what rank r sends to everybody; `clamp` = the most a sender's list holds.
+// out_at[r] / in_at[r]: record offsets of the message to / from rank r in the sender's packed buffer / the receive buffer;
+// n_out[r] / n_in[r]: records; returns the total received.
+size_t exchange_layout(const int* m, int G, int me, long long clamp, bool packed_send, size_t send_stride, size_t* out_at, size_t* n_out,
+                       size_t* in_at, size_t* n_in) {
+    size_t out_run = 0, in_run = 0;
+    for (int r = 0; r < G; ++r) {
+        const long long out = r == me ? 0 : std::min<long long>(std::max(0, m[me * G + r]), clamp);
+        const long long in = r == me ? 0 : std::min<long long>(std::max(0, m[r * G + me]), clamp);
+        n_out[r] = size_t(out);
+        n_in[r] = size_t(in);
+        out_at[r] = packed_send ? out_run : size_t(r) * send_stride;
+        in_at[r] = in_run;
+        out_run += size_t(out);
+        in_run += size_t(in);
+    }
+    return in_run;
+}
+
+// ---- production: the exchanges through the handle's transport (RCCL; or the one-device transport), on the handle's stream
 static int pass(NbodyHandle* h, float dt, bool is_step) {
     State& s = *h->let;
     if (s.G > 1 && !h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    const bool comm = h->comm_ready;   // (a world of one WITH a communicator still runs every collective: the 1-rank rehearsal)
+    size_t out_at[kMaxRanks], n_out[kMaxRanks], in_at[kMaxRanks], n_in[kMaxRanks];
     int rc = phase0(h, s, dt, is_step);
     if (rc) return rc;
-    if (s.G > 1) {   // exchange 0: the counts first (row r = what rank r sends to everybody), then the migrants themselves
-        NCCL_TRY(h, ncclAllGather(s.d_send_count, s.d_mig_matrix, size_t(s.G), ncclInt32, h->comm, h->stream));
+    if (comm) {   // exchange 0: the counts first (row r = what rank r sends to everybody), then the migrants themselves
+        HIP_TRY(h, hipMemcpyAsync(s.d_mig_matrix + size_t(s.me) * s.G, s.d_send_count, sizeof(int) * s.G, hipMemcpyDeviceToDevice, h->stream));
+        TP_TRY(h, h->tp->all_gather(s.d_mig_matrix, sizeof(int) * size_t(s.G), h->stream));
         HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_mig_matrix, sizeof(int) * s.G * s.G, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        size_t total_in = 0;
-        for (int r = 0; r < s.G; ++r) if (r != s.me) total_in += size_t(std::max(0, s.h_pin[r * s.G + s.me]));
+        const size_t total_in = exchange_layout(s.h_pin, s.G, s.me, (long long)h->sh.seg_cap, true, 0, out_at, n_out, in_at, n_in);
         rc = ensure_mig_recv(h, s, total_in, 0);
         if (rc) return rc;
-        NCCL_TRY(h, ncclGroupStart());
-        size_t out_at = 0, in_at = 0;
+        TP_TRY(h, h->tp->group_begin());
         for (int r = 0; r < s.G; ++r) {
-            const size_t out = size_t(std::max(0, s.h_pin[s.me * s.G + r]));   // (0 for r == me: a body that stays is not counted)
-            const size_t in = r == s.me ? 0 : size_t(std::max(0, s.h_pin[r * s.G + s.me]));
-            if (r != s.me && out > 0) NCCL_TRY(h, ncclSend(s.d_send_mig + out_at, out * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
-            if (in > 0) NCCL_TRY(h, ncclRecv(s.d_recv_mig + in_at, in * sizeof(Migrant), ncclChar, r, h->comm, h->stream));
-            out_at += out; in_at += in;
+            if (n_out[r] > 0) TP_TRY(h, h->tp->send(s.d_send_mig + out_at[r], n_out[r] * sizeof(Migrant), r, h->stream));
+            if (n_in[r] > 0) TP_TRY(h, h->tp->recv(s.d_recv_mig + in_at[r], n_in[r] * sizeof(Migrant), r, h->stream));
         }
-        NCCL_TRY(h, ncclGroupEnd());
+        TP_TRY(h, h->tp->group_end());
         s.mig_in = int(total_in);
     }
     rc = phase1(h, s);
     if (rc) return rc;
-    if (s.G > 1) NCCL_TRY(h, ncclAllGather(s.d_ends + s.me, s.d_ends, sizeof(EndInfo), ncclChar, h->comm, h->stream));   // exchange 1
+    if (comm) TP_TRY(h, h->tp->all_gather(s.d_ends, sizeof(EndInfo), h->stream));   // exchange 1
     rc = phase2(h, s);
     if (rc) return rc;
-    if (s.G > 1) NCCL_TRY(h, ncclAllGather(s.d_rb + s.me, s.d_rb, sizeof(RoundB), ncclChar, h->comm, h->stream));         // exchange 2
+    if (comm) TP_TRY(h, h->tp->all_gather(s.d_rb, sizeof(RoundB), h->stream));      // exchange 2
     rc = phase3(h, s);
     if (rc) return rc;
     std::fill(s.recv_n.begin(), s.recv_n.end(), 0);
-    if (s.G > 1) {   // exchange 3: the counts first (row r of the matrix = what rank r sends to everybody), then the records
-        NCCL_TRY(h, ncclAllGather(s.d_let_count, s.d_let_matrix, size_t(s.G), ncclInt32, h->comm, h->stream));
+    if (comm) {   // exchange 3: the counts first (row r of the matrix = what rank r sends to everybody), then the records
+        HIP_TRY(h, hipMemcpyAsync(s.d_let_matrix + size_t(s.me) * s.G, s.d_let_count, sizeof(int) * s.G, hipMemcpyDeviceToDevice, h->stream));
+        TP_TRY(h, h->tp->all_gather(s.d_let_matrix, sizeof(int) * size_t(s.G), h->stream));
         HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_let_matrix, sizeof(int) * s.G * s.G, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        size_t total_in = 0;
-        for (int r = 0; r < s.G; ++r) { s.recv_n[r] = r == s.me ? 0 : s.h_pin[r * s.G + s.me]; total_in += size_t(s.recv_n[r]); }
+        for (int a = 0; a < s.G; ++a)
+            for (int b = 0; b < s.G; ++b)
+                if (a != b && size_t(std::max(0, s.h_pin[a * s.G + b])) > s.let_stride)   // (every rank sees the same matrix: all of them stop here)
+                    return fail(h, NBODY_ERR_CAPACITY, "spatial shards: export list overflow (rank " + std::to_string(a) + " has " + std::to_string(s.h_pin[a * s.G + b]) +
+                                                           " nodes for rank " + std::to_string(b) + ", its list holds " + std::to_string(s.let_stride) + ")");
+        const size_t total_in = exchange_layout(s.h_pin, s.G, s.me, (long long)s.let_stride, false, s.let_stride, out_at, n_out, in_at, n_in);
+        for (int r = 0; r < s.G; ++r) s.recv_n[r] = int(n_in[r]);
         if (total_in > s.let_recv_cap) {
             if (s.d_let_recv) (void)hipFree(s.d_let_recv);
             s.d_let_recv = nullptr; s.let_recv_cap = 0;
             HIP_TRY(h, hipMalloc(&s.d_let_recv, (total_in + total_in / 4 + 1024) * sizeof(LetRecord)));
             s.let_recv_cap = total_in + total_in / 4 + 1024;
         }
-        NCCL_TRY(h, ncclGroupStart());
-        size_t at = 0;
+        TP_TRY(h, h->tp->group_begin());
         for (int r = 0; r < s.G; ++r) {
-            if (r == s.me) continue;
-            const int out = std::min<long long>(s.h_pin[s.me * s.G + r], (long long)s.let_stride);
-            if (out > 0) NCCL_TRY(h, ncclSend(s.d_let_send + size_t(r) * s.let_stride, size_t(out) * sizeof(LetRecord), ncclChar, r, h->comm, h->stream));
-            if (s.recv_n[r] > 0) NCCL_TRY(h, ncclRecv(s.d_let_recv + at, size_t(s.recv_n[r]) * sizeof(LetRecord), ncclChar, r, h->comm, h->stream));
-            at += size_t(s.recv_n[r]);
+            if (n_out[r] > 0) TP_TRY(h, h->tp->send(s.d_let_send + out_at[r], n_out[r] * sizeof(LetRecord), r, h->stream));
+            if (n_in[r] > 0) TP_TRY(h, h->tp->recv(s.d_let_recv + in_at[r], n_in[r] * sizeof(LetRecord), r, h->stream));
         }
-        NCCL_TRY(h, ncclGroupEnd());
-        launch_scatter(h->stream, s.d_let_recv, int(total_in), s.d_global, s.global_cap);
+        TP_TRY(h, h->tp->group_end());
+        if (total_in > 0) launch_scatter(h->stream, s.d_let_recv, int(total_in), s.d_global, s.global_cap);
     }
     rc = phase4(h, s, dt, is_step);
     if (rc) return rc;

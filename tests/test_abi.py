@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(nb):
     lib = ctypes.CDLL(nb.LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"libnbody_hip.so lacks {missing}"
-    assert lib.nbody_abi_version() == 3
+    assert lib.nbody_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header(nb):
