@@ -14,9 +14,13 @@ configs[2] (65 536-body Barnes-Hut, theta = 0.5) run both ways -- octree built o
 (north_star's configuration) and built on the device -- each with its own step time, build / copy /
 walk split, node visits and roofline.  With N ranks the bodies are split into N contiguous index
 blocks; every rank exchanges its half-drifted positions once per step with an RCCL all-gather issued by
-the library itself (torch.distributed/gloo is control plane only: rendezvous, the ncclUniqueId
-broadcast, barriers and the max-over-ranks of the wall time).  BASELINE's metric is quoted at
-N = 65 536 on 1/2/4/8 GPUs, i.e. total work fixed: "strong".
+the library itself.  The control plane -- the 128-byte communicator id from rank 0, barriers, the
+max-over-ranks of the wall time -- is nbody-llm_amd/rendezvous.py (stdlib sockets): a rank process never
+imports torch, so libnbody_hip.so runs on the /opt/rocm HIP and RCCL it was compiled against (torch
+bundles its own, older, under the same SONAMEs); `torch.distributed.run` is only the launcher that sets
+RANK / WORLD_SIZE / MASTER_PORT.  BASELINE's metric is quoted at N = 65 536 on 1/2/4/8 GPUs, i.e. total
+work fixed: "strong".  A one-GPU box rehearses the N > 1 path with NBODY_BENCH_DEVICE=0 NBODY_TRANSPORT=ipc
+(all ranks on device 0 over the library's one-device transport; RCCL refuses two ranks on one device).
 
 What bounds the kernels: the all-pairs kernel is fp32-VALU bound (O(N) data for
 O(N^2) arithmetic), so `roofline.bound` is "fp32-valu" and the HBM fraction BASELINE asks for rides
@@ -82,6 +86,9 @@ def parse():
     ap.add_argument("--large-steps", type=int, default=5)
     ap.add_argument("--driver-n", type=int, default=100000, help="one GPU: disc bodies of the reference driver's workload (0: leave it out)")
     ap.add_argument("--main-timeout", type=float, default=600.0, help="N > 1 GPUs: seconds before the metric's own run is declared stuck")
+    ap.add_argument("--preheat", type=int, default=-1,
+                    help="untimed steps before the warm-up, reported as preheat_steps: the chip settles on the clock it holds under this kernel "
+                         "only after ~50 steps (DESIGN.md 3.2), and the driver's invocation is 5 + 20 steps; -1: 100 at the metric's size, else 0")
     ap.add_argument("--seed", type=int, default=20250523)
     return ap.parse_args()
 
@@ -201,8 +208,8 @@ def bh_roofline(n_local, kernel_ms, launches, visits_per_launch, tree):
     }
 
 
-def run(nb, args, workload, tree, ics, box, st, rank, world, local_rank, dist, ident_fn):
-    """W warm-up + K timed steps of one workload; returns (elapsed, stats, n_after)."""
+def run(nb, args, workload, tree, ics, box, st, rank, world, local_rank, rdzv, ident_fn, preheat=0):
+    """[preheat +] W warm-up + K timed steps of one workload; returns (elapsed, stats, n_after)."""
     n = len(ics)
     method = nb.BRUTE_FORCE if workload == "bf" else nb.BARNES_HUT
     math_mode = nb.FAST if args.math == "fast" else nb.STRICT
@@ -210,16 +217,18 @@ def run(nb, args, workload, tree, ics, box, st, rank, world, local_rank, dist, i
                         rank=rank, world_size=world,
                         tree_build=nb.TREE_DEVICE if tree == "device" else nb.TREE_HOST)
     sim.settings = nb.Settings(**st)
-    if dist is not None and (world > 1 or os.environ.get("NBODY_BENCH_FORCE_COMM")):
+    if rdzv is not None and (world > 1 or os.environ.get("NBODY_BENCH_FORCE_COMM")):
         sim.comm_init(ident_fn())
     sim.init()
 
     def barrier():
         sim.sync()
-        if dist is not None:
-            dist.barrier()
+        if rdzv is not None:
+            rdzv.barrier()
             sim.sync()
 
+    if preheat > 0:
+        sim.steps(preheat)
     sim.steps(args.warmup)
     sim.set_profiling(True)
     sim.reset_stats()
@@ -235,7 +244,7 @@ def run(nb, args, workload, tree, ics, box, st, rank, world, local_rank, dist, i
     return elapsed, stats, n_after
 
 
-def run_spatial(nb, args, box, st, rank, world, local_rank, dist, ident_fn):
+def run_spatial(nb, args, box, st, rank, world, local_rank, rdzv, ident_fn):
     """configs[4]: Barnes-Hut over spatial shards with the halo exchange of nodes (NBODY_SHARD_SPATIAL, nbody_let.cpp),
     one rank per GPU over RCCL.  Returns this rank's record."""
     n = args.spatial_n
@@ -249,11 +258,11 @@ def run_spatial(nb, args, box, st, rank, world, local_rank, dist, ident_fn):
     sim.set_profiling(True)
     sim.reset_stats()
     sim.sync()
-    dist.barrier()
+    rdzv.barrier()
     t0 = time.perf_counter()
     sim.steps(args.spatial_steps)
     sim.sync()
-    dist.barrier()
+    rdzv.barrier()
     elapsed = time.perf_counter() - t0
     stats, ls = sim.stats(), sim.let_stats()
     own = len(sim)
@@ -298,35 +307,45 @@ def main():
             sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    dist = None
+    rdzv = None
     json_fd = None
-    if "RANK" in os.environ and "MASTER_PORT" in os.environ:  # launched by torch.distributed.run (any N)
-        # gloo and RCCL print connection/version banners on stdout: stdout is pointed at stderr for
-        # the whole run and the one JSON line goes to the original descriptor at the end
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # by torch.distributed.run (any N)
+    if launched:
+        # RCCL prints connection/version banners on stdout: stdout is pointed at stderr for the whole run and the one JSON
+        # line goes to the original descriptor at the end
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
-        # torch bundles its own ROCm runtime libraries under the same SONAMEs as /opt/rocm's; a
-        # process must end up with ONE set, so torch goes first and libnbody_hip.so binds to what is
-        # already loaded (the other order aborts at exit with a double free).  N = 1 never imports torch.
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist  # control plane only (gloo)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def emit(line_obj):
+        data = (json.dumps(line_obj) + "\n").encode()
+        if json_fd is not None:
+            os.write(json_fd, data)
+        else:
+            sys.stdout.write(data.decode())
+            sys.stdout.flush()
+
+    def error_line(text):
+        return {"metric": "pairwise_interactions_per_sec", "value": None, "unit": "interactions/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "higher_is_better": True, "error": text}
 
     nb = graft.load_package()
     if nb.device_count() < 1:
         sys.exit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if launched:
+        from nbody_llm_amd.rendezvous import Rendezvous   # stdlib control plane: no torch in a rank process
+        rdzv = Rendezvous(rank, world, timeout=float(os.environ.get("NBODY_BENCH_RDZV_TIMEOUT", "300")))
 
     n = args.n
     box = ((0.0, 0.0, 0.0), 64.0)
     theta2 = args.theta * args.theta
     st = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=theta2)
     ics = nb.plummer(n, seed=args.seed)
+    preheat = args.preheat if args.preheat >= 0 else (100 if (args.workload == "bf" and n == 65536 and args.math == "fast") else 0)
 
     def ident_fn():
-        ident = [nb.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        return ident[0]
+        # (NBODY_TRANSPORT=ipc in the environment makes this the id of the one-device transport: the one-GPU rehearsal)
+        return rdzv.bcast_bytes(nb.comm_unique_id() if rank == 0 else None)
 
     main_guard = None
     if world > 1:
@@ -336,32 +355,29 @@ def main():
 
         def stuck():
             if rank == 0:
-                line = json.dumps({"metric": "pairwise_interactions_per_sec", "value": None, "unit": "interactions/s", "n_gpus": world,
-                                   "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-                                   "error": f"no result within {args.main_timeout:.0f} s (a rank stuck in the exchange?)"})
-                os.write(json_fd if json_fd is not None else 1, (line + "\n").encode())
+                emit(error_line(f"no result within {args.main_timeout:.0f} s (a rank stuck in the exchange?)"))
             os._exit(3)
 
         main_guard = threading.Timer(args.main_timeout, stuck)
         main_guard.daemon = True
         main_guard.start()
-    elapsed, stats, n_after = run(nb, args, args.workload, args.tree, ics, box, st, rank, world, local_rank, dist, ident_fn)
-
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed, float(stats.interactions), stats.force_kernel_ms, float(stats.force_launches),
-                          float(stats.node_visits), float(stats.force_kernel_interactions)], dtype=torch.float64)
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        elapsed = max(float(g[0]) for g in gathered)
-        interactions = sum(float(g[1]) for g in gathered)
-        kernel_ms = max(float(g[2]) for g in gathered)   # the slowest rank's kernel time
-        launches = float(gathered[0][3])
-        visits = sum(float(g[4]) for g in gathered)
-        k_inter = float(gathered[0][5])                  # rank 0's dominant-kernel interactions
-    else:
-        interactions, kernel_ms, launches, visits = float(stats.interactions), stats.force_kernel_ms, float(stats.force_launches), float(stats.node_visits)
-        k_inter = float(stats.force_kernel_interactions)
+    try:
+        elapsed, stats, n_after = run(nb, args, args.workload, args.tree, ics, box, st, rank, world, local_rank, rdzv, ident_fn, preheat=preheat)
+        mine = [elapsed, float(stats.interactions), stats.force_kernel_ms, float(stats.force_launches), float(stats.node_visits),
+                float(stats.force_kernel_interactions)]
+        gathered = rdzv.allgather(mine) if rdzv is not None else [mine]
+    except BaseException as e:  # noqa: BLE001 -- a rank that raises must not leave the driver without a line, nor its peers in a collective
+        if rank == 0:
+            emit(error_line(f"rank 0: {type(e).__name__}: {e}"))
+        else:
+            sys.stderr.write(f"bench.py rank {rank}: {type(e).__name__}: {e}\n")
+        os._exit(1)   # (closes this rank's sockets: a peer blocked in the rendezvous sees the connection go and lands here too)
+    elapsed = max(float(g[0]) for g in gathered)
+    interactions = sum(float(g[1]) for g in gathered)
+    kernel_ms = max(float(g[2]) for g in gathered)   # the slowest rank's kernel time
+    launches = float(gathered[0][3])
+    visits = sum(float(g[4]) for g in gathered)
+    k_inter = float(gathered[0][5])                  # rank 0's dominant-kernel interactions
 
     if main_guard is not None:
         main_guard.cancel()
@@ -377,6 +393,7 @@ def main():
             "metric": "pairwise_interactions_per_sec", "value": value, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "steps_per_sec": args.steps / elapsed,
+            "preheat_steps": preheat,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": ("configs[1]: 65 536-body brute force" if (args.workload == "bf" and n == 65536) else
@@ -386,8 +403,9 @@ def main():
                 "math": args.math, "ics": f"plummer seed={args.seed}", "dt": st["dt"], "g_soft": st["g_soft"],
                 "theta2": theta2 if args.workload == "bh" else None, "box_width": box[1],
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} index-block shards; per step one RCCL all-gather of positions and one "
-                               f"send/recv round of partial sums (every pair between shards evaluated once)",
+                               f"{world} index-block shards; per step one all-gather of positions and one "
+                               f"send/recv round of partial sums (every pair between shards evaluated once); transport "
+                               f"{'ipc (all ranks on one device: rehearsal)' if os.environ.get('NBODY_TRANSPORT') == 'ipc' else 'rccl'}",
                 "bodies_left_in_box": n_after,
             },
             "roofline": roofline,
@@ -408,7 +426,7 @@ def main():
     # configs[4] beside the metric's line when there is more than one GPU: Barnes-Hut over spatial shards.  Its RCCL
     # exchange runs with > 1 rank only here (a one-GPU box cannot rehearse it), so it is fenced: an error or a rank that
     # does not come back within --spatial-timeout leaves a note in the line instead of taking the metric with it.
-    extras = world > 1 or (dist is not None and os.environ.get("NBODY_BENCH_FORCE_EXTRAS"))   # (the env switch: a 1-rank rehearsal of this block)
+    extras = world > 1 or (rdzv is not None and os.environ.get("NBODY_BENCH_FORCE_EXTRAS"))   # (the env switch: a 1-rank rehearsal of this block)
     if args.workload == "bf" and extras and not args.no_bh and (args.spatial_n > 0 or args.large_n > 0):
         import threading
 
@@ -417,7 +435,7 @@ def main():
                 result.setdefault("bf_large", {"error": f"no result within {args.spatial_timeout:.0f} s"})
                 result["bh_spatial"] = {"error": f"no result within {args.spatial_timeout:.0f} s"}
                 result["cpu_baseline"] = None
-                os.write(json_fd if json_fd is not None else 1, (json.dumps(result) + "\n").encode())
+                emit(result)
             os._exit(0)
 
         guard = threading.Timer(args.spatial_timeout, give_up)
@@ -430,12 +448,11 @@ def main():
                 import copy
                 a3 = copy.copy(args)
                 a3.steps, a3.warmup = args.large_steps, 1
-                e3, s3, _ = run(nb, a3, "bf", args.tree, nb.plummer(args.large_n, seed=args.seed), box, st, rank, world, local_rank, dist, ident_fn)
+                e3, s3, _ = run(nb, a3, "bf", args.tree, nb.plummer(args.large_n, seed=args.seed), box, st, rank, world, local_rank, rdzv, ident_fn)
                 big = {"elapsed": e3, "interactions": float(s3.interactions), "kernel_ms": s3.force_kernel_ms / max(1.0, float(s3.force_launches))}
             except Exception as e:  # noqa: BLE001
                 big = {"error": f"{type(e).__name__}: {e}"}
-            bigs = [None] * world
-            dist.all_gather_object(bigs, big)
+            bigs = rdzv.allgather(big)
             if rank == 0:
                 bad = [b for b in bigs if b is None or "error" in b]
                 if bad:
@@ -443,8 +460,8 @@ def main():
                 else:
                     el = max(b["elapsed"] for b in bigs)
                     result["bf_large"] = {
-                        "workload": f"configs[3]: {args.large_n}-body brute force, {world} index-block shards, RCCL all-gather of positions + "
-                                    "one send/recv round of partial sums per step",
+                        "workload": f"configs[3]: {args.large_n}-body brute force, {world} index-block shards, all-gather of positions + "
+                                    f"one send/recv round of partial sums per step (transport {'ipc' if os.environ.get('NBODY_TRANSPORT') == 'ipc' else 'rccl'})",
                         "ms_per_step": 1e3 * el / args.large_steps, "steps_per_sec": args.large_steps / el,
                         "interactions_per_sec": sum(b["interactions"] for b in bigs) / el, "steps": args.large_steps,
                         "cross_kernel_ms_per_rank": [b["kernel_ms"] for b in bigs],
@@ -453,13 +470,12 @@ def main():
         rec = None
         try:
             if args.spatial_n > 0:
-                rec = run_spatial(nb, args, box, dict(st, theta2=theta2), rank, world, local_rank, dist, ident_fn)
+                rec = run_spatial(nb, args, box, dict(st, theta2=theta2), rank, world, local_rank, rdzv, ident_fn)
             else:
                 rec = {"skipped": True}
         except Exception as e:  # noqa: BLE001 -- whatever it is, the metric's line must still go out
             rec = {"error": f"{type(e).__name__}: {e}"}
-        recs = [None] * world
-        dist.all_gather_object(recs, rec)
+        recs = rdzv.allgather(rec)
         guard.cancel()
         if rank == 0:
             bad = [r for r in recs if r is None or "error" in r]
@@ -472,7 +488,7 @@ def main():
                 k = args.spatial_steps
                 result["bh_spatial"] = {
                     "workload": f"configs[4]: {args.spatial_n}-body Barnes-Hut theta={args.theta}, {world} spatial shards (Morton-key ranges), "
-                                "halo exchange of tree nodes over RCCL",
+                                f"halo exchange of tree nodes (transport {'ipc' if os.environ.get('NBODY_TRANSPORT') == 'ipc' else 'rccl'})",
                     "ms_per_step": 1e3 * el / k, "steps_per_sec": k / el, "interactions_per_sec": sum(r["interactions"] for r in recs) / el,
                     "tree_nodes": recs[0]["tree_nodes"], "steps": k,
                     "per_rank": [{kk: r[kk] for kk in ("bodies", "nodes_local", "nodes_sent", "nodes_received", "bytes_sent", "bytes_allgather",
@@ -522,14 +538,10 @@ def main():
                 result["bh"]["cpu_baseline"] = cpu_baseline(orc, ics, st, box, "bh")
         else:
             result["cpu_baseline"] = None
-        line = json.dumps(result)
-        if json_fd is not None:
-            os.write(json_fd, (line + "\n").encode())
-        else:
-            print(line, flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        emit(result)
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":

@@ -260,6 +260,15 @@ int nbody_debug_let_set_prune(NbodyHandle* h, int prune);
 int nbody_host_cross_plan(int rank, int world, int seg_cap, int n_own, int* ipt, int* n_sets, int* n_parts, int* parts,
                           int* n_recv, int* recv_from);
 
+/* ---- host-only entry (no device needed): message layout of the spatial step's variable-size rounds ---- */
+/* matrix[r * world + q] = records rank r sends to rank q (all-gathered, the same on every rank).  For `rank`: out_at / n_out
+ * [world] = record offset (in its packed send buffer, or q * send_stride when !packed_send) and count of the message to
+ * each rank; in_at / n_in [world] = offset in its receive buffer and count of the message from each rank; counts are
+ * clamped to `clamp` on BOTH sides of every pair (the byte counts of a send and of the receive that meets it are the
+ * same expression). */
+int nbody_host_exchange_layout(const int* matrix, int world, int rank, long long clamp, int packed_send, size_t send_stride,
+                               size_t* out_at, size_t* n_out, size_t* in_at, size_t* n_in, size_t* total_in);
+
 /* ---- host-only entry (no device needed): the octree build alone ------------------------------ */
 /* BarnesHutSimulation::build_tree (barnes_hut.rs:143-183) + linearisation, as the Barnes-Hut step
  * runs it.  pos4 = n records {x,y,z,m}.  Output arrays hold `cap` nodes (com_mass: 4 floats per

@@ -69,7 +69,7 @@ DECLARED_SYMBOLS = [
     "nbody_tree_export_f64", "nbody_ic_plummer_f64", "nbody_ic_disc_f64",
     "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
     "nbody_debug_let_bounds", "nbody_debug_let_set_balance",
-    "nbody_comm_local_id", "nbody_comm_transport",
+    "nbody_comm_local_id", "nbody_comm_transport", "nbody_host_exchange_layout",
 ]
 
 
@@ -163,6 +163,7 @@ _sig("nbody_debug_let_exchange", _i, _H, _H, _i)
 _sig("nbody_debug_let_set_prune", _i, _H, _i)
 _sig("nbody_debug_let_bounds", _i, _H, C.c_void_p)
 _sig("nbody_debug_let_set_balance", _i, _H, _i)
+_sig("nbody_host_exchange_layout", _i, C.c_void_p, _i, _i, C.c_longlong, _i, _sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_sz))
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
 
@@ -505,6 +506,19 @@ def host_cross_plan(rank: int, world: int, seg_cap: int, n_own: int) -> dict:
     if rc:
         raise NbodyError(rc, "nbody_host_cross_plan")
     return dict(ipt=ipt.value, n_sets=a.value, parts=parts[: npart.value].copy(), recv_from=recv[: nrecv.value].copy())
+
+
+def host_exchange_layout(matrix: np.ndarray, rank: int, clamp: int, packed_send: bool, send_stride: int = 0) -> dict:
+    """Host-only: message offsets and counts of a variable-size round of the spatial step, for one rank."""
+    m = np.ascontiguousarray(matrix, dtype=np.int32)
+    G = m.shape[0]
+    arr = {k: np.zeros(G, np.uint64) for k in ("out_at", "n_out", "in_at", "n_in")}
+    tot = C.c_size_t(0)
+    rc = lib.nbody_host_exchange_layout(m.ctypes.data, G, rank, int(clamp), int(bool(packed_send)), int(send_stride), arr["out_at"].ctypes.data,
+                                        arr["n_out"].ctypes.data, arr["in_at"].ctypes.data, arr["n_in"].ctypes.data, C.byref(tot))
+    if rc:
+        raise NbodyError(rc, "nbody_host_exchange_layout")
+    return dict({k: v.astype(np.int64) for k, v in arr.items()}, total_in=int(tot.value))
 
 
 def comm_unique_id() -> bytes:

@@ -1480,6 +1480,8 @@ int nbody_energy(NbodyHandle* h, double* kinetic, double* potential) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::energy(h, kinetic, potential);
+    if (h->let && h->cfg.world_size > 1)   // (a spatial rank sees its own bodies only: the pair sum over them is not the world's energy)
+        return fail(h, NBODY_ERR_INVALID, "nbody_energy is not supported on NBODY_SHARD_SPATIAL handles of a world of more than one rank");
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1513,6 +1515,8 @@ int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* sk
         if (com_mass || width) return fail(h, NBODY_ERR_INVALID, "f64 handle: use nbody_tree_export_f64");
         return nbody64::tree_export(h, nullptr, nullptr, skip, cap, n_nodes);
     }
+    if (h->let)   // (a spatial rank holds its slice and what it imported, never the whole tree)
+        return fail(h, NBODY_ERR_INVALID, "nbody_tree_export is not supported on NBODY_SHARD_SPATIAL handles");
     {
         int rc = use_device(h);
         if (rc) return rc;
@@ -1741,6 +1745,16 @@ int nbody_host_cross_plan(int rank, int world, int seg_cap, int n_own, int* ipt,
         }
     if (n_recv) *n_recv = p.n_recv;
     if (recv_from) for (int i = 0; i < p.n_recv; ++i) recv_from[i] = p.recv_from[i];
+    return NBODY_OK;
+}
+
+// Host-only entry (no device needed): where the variable-size rounds of the spatial step (migrants, tree nodes) put their
+// messages, from the all-gathered G x G count matrix -- the arithmetic sender and receiver of every pair share.
+int nbody_host_exchange_layout(const int* matrix, int world, int rank, long long clamp, int packed_send, size_t send_stride,
+                               size_t* out_at, size_t* n_out, size_t* in_at, size_t* n_in, size_t* total_in) {
+    if (!matrix || world < 1 || world > 16 || rank < 0 || rank >= world || !out_at || !n_out || !in_at || !n_in) return NBODY_ERR_INVALID;
+    const size_t t = nbody::let::exchange_layout(matrix, world, rank, clamp, packed_send != 0, send_stride, out_at, n_out, in_at, n_in);
+    if (total_in) *total_in = t;
     return NBODY_OK;
 }
 

@@ -17,6 +17,9 @@ int step(NbodyHandle* h, float dt);         // one step with the RCCL exchanges
 int update_forces(NbodyHandle* h);
 int stats(NbodyHandle* h, NbodyLetStats* out);
 int reset_stats(NbodyHandle* h);
+// offsets and record counts of the variable-size rounds, from the all-gathered count matrix (host arithmetic)
+size_t exchange_layout(const int* m, int G, int me, long long clamp, bool packed_send, size_t send_stride, size_t* out_at, size_t* n_out,
+                       size_t* in_at, size_t* n_in);
 int check_flags(NbodyHandle* h);            // turns the device's sticky flags into an error code (synchronises)
 // one-process emulation of G ranks (tests): the phases between the exchanges, and the exchanges as copies
 int debug_phase(NbodyHandle* h, int phase, float dt);

@@ -2,7 +2,8 @@
 
 What is exercised is the sharding SCHEME the HIP library implements (nbody_upload's contiguous
 index blocks, one all-gather of half-drifted positions + live counts per step, per-shard retain)
-and bench.py's control plane (rendezvous on 127.0.0.1, unique-id broadcast, max-over-ranks): each
+and the control-plane pattern of a rank process (id from rank 0 to everybody, max-over-ranks; bench.py's own
+control plane, nbody-llm_amd/rendezvous.py, is covered by tests/test_rendezvous.py): each
 rank advances its own block with the oracle's row-wise force over the gathered positions, and the
 concatenation must equal the unsharded oracle bit for bit.  (The device kernels themselves are
 covered by tests/test_sharded_gpu.py.)"""

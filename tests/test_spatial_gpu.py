@@ -302,10 +302,16 @@ def test_spatial_handles_refuse_what_they_do_not_support(gpu):
             sim.add_point(ics[0])
         with pytest.raises(nb.NbodyError):
             sim.clone()
+        for call in (sim.tree, sim.energy):   # a spatial rank holds neither the whole tree nor all bodies: no silent partial answers
+            with pytest.raises(nb.NbodyError) as e:
+                call()
+            assert e.value.code == nb.NBODY_ERR_INVALID
 
 
 def test_spatial_single_rank_with_a_communicator(gpu):
-    """The RCCL code path with a world of one (ncclCommInitRank, the all-gathers): results = the plain device-tree run."""
+    """A world of one WITH a communicator runs every collective of the step (the exchanges are guarded by "has a
+    communicator", not by G > 1): ncclCommInitRank, the in-place all-gathers of counts and tables, empty send/recv
+    groups; results = the plain device-tree run."""
     nb = gpu
     st = nb.Settings(1.0, 0.01, 1e-3, 0.25)
     ics = nb.plummer(3000, seed=65)
