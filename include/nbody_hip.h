@@ -218,6 +218,10 @@ typedef struct NbodyLetStats {
     double phase_ms[5];         /* device time of the five phases between the exchanges, summed over the passes made with
                                  * nbody_set_profiling(h, 1): drift + retain + pick migrants | take them in, keys, sort |
                                  * emit the slice + spanning-cell table | finish + flag + pack the export | walk + kick */
+    uint64_t host_syncs;        /* host synchronisations inside the passes (steady state: one per pass, where the export counts are read) */
+    uint64_t migrant_respills;  /* passes whose migrants did not fit the sizes their messages were posted with and made the round twice */
+    uint64_t node_array_peak_bytes;  /* most bytes of node records this rank held at once: its own slice + what it imported */
+    uint64_t node_array_bytes;       /* bytes of the global-index array those records are scattered over (address range, sparsely written) */
 } NbodyLetStats;
 int nbody_let_stats(NbodyHandle* h, NbodyLetStats* out);
 

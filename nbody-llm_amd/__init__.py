@@ -83,7 +83,8 @@ class NbodyConfig(C.Structure):
 
 class NbodyLetStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("steps", "bodies_migrated", "nodes_local", "nodes_global", "nodes_sent", "nodes_received",
-                                          "bytes_sent", "bytes_allgather_equivalent")] + [("phase_ms", C.c_double * 5)]
+                                          "bytes_sent", "bytes_allgather_equivalent")] + [("phase_ms", C.c_double * 5)] + \
+               [(k, C.c_uint64) for k in ("host_syncs", "migrant_respills", "node_array_peak_bytes", "node_array_bytes")]
 
 
 class NbodyStats(C.Structure):

@@ -8,7 +8,9 @@ namespace let {
 constexpr int kLevels = 21;     // levels of the device build's keys
 constexpr int kMaxRanks = 16;
 
-enum { kFlagDeep = 1, kFlagNodeCapLocal = 2, kFlagCapacity = 8, kFlagNodeCap = 16 };
+enum { kFlagDeep = 1, kFlagNodeCapLocal = 2, kFlagCapacity = 8, kFlagNodeCap = 16,
+       kFlagMigSpill = 32 };   // more migrants between some pair of ranks than the size its message was posted with (the
+                               // step's migrant round is then made again with the exact sizes: nbody_let.cpp)
 
 struct Migrant {                // a body on its way to the rank that owns its key range (64 bytes)
     float4 pos, vel, acc;
@@ -48,6 +50,20 @@ struct LetRecord {              // an exported node (32 bytes): the record; b.z 
 void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float center[3], float width, const unsigned long long* bounds,
                      int G, int me, unsigned char* dest_of, Migrant* send, int* send_count, int* send_off, int* cursor, bool after_drift);
 void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, int n_in, int G, int* flags, int* new_count, int* send_count);
+// The migrant round with message sizes fixed BEFORE the counts are known to the host (pred[a * G + b] = records the message
+// from rank a to rank b is posted with; the same matrix on every rank): k_let_spec raises kFlagMigSpill on every rank alike
+// if some pair has more, launch_slot_migrants copies the packed emigrants into one slot per destination, and
+// launch_append_slots takes the immigrants out of the receive slots (actual counts from the all-gathered matrix) unless
+// the flag is up.  slots_in_upper = sum of the predicted sizes of this rank's incoming messages.
+void launch_spec_check(hipStream_t s, const int* matrix, const int* pred, int G, int* flags);
+void launch_slot_migrants(hipStream_t s, const Migrant* packed, int n_packed_upper, const int* send_off, const int* pred, int G, int me, Migrant* slots);
+void launch_append_slots(hipStream_t s, const Shard& sh, const Migrant* slots_in, int slots_in_upper, const int* matrix, const int* pred, int G, int me,
+                         int* flags, int* new_count, int* send_count);
+// everything the host wants to know once per step, gathered into one block for one copy:
+// report[0..G*G) export counts | [G*G..2 G*G) migrant counts | offsets[G+1] | tree_info[3] | flags[4]
+void launch_report(hipStream_t s, const int* let_matrix, const int* mig_matrix, const int* offsets, const int* tree_info, const int* flags, int G,
+                   int* report);
+inline int report_ints(int G) { return 2 * G * G + (G + 1) + 3 + 4; }
 void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
                  unsigned long long* weight_sum, EndInfo* mine);
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge);

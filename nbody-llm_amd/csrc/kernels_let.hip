@@ -132,12 +132,66 @@ __global__ __launch_bounds__(256) void k_let_append(float4* __restrict__ pos, fl
     pos[d] = m.pos; vel[d] = m.vel; acc[d] = m.acc; ids[d] = m.id;
 }
 __global__ void k_let_commit_count(int* __restrict__ count, const int* __restrict__ new_count, int* __restrict__ send_count, int G,
-                                   int* __restrict__ migrated) {
+                                   int* __restrict__ migrated, const int* __restrict__ flags) {
+    if (flags && (*flags & kFlagMigSpill)) return;   // the migrant round did not fit its posted sizes: it is made again, nothing is committed
     if (threadIdx.x == 0) *count = *new_count;
     if (int(threadIdx.x) < G) {
         if (send_count[threadIdx.x] > 0) atomicAdd(migrated, send_count[threadIdx.x]);   // bookkeeping (NbodyLetStats.bodies_migrated)
         send_count[threadIdx.x] = 0;   // ready for the next step's classification
     }
+}
+
+// ---- the migrant round with message sizes posted before the host knows the counts (see kernels_let.h)
+__global__ void k_let_spec(const int* __restrict__ matrix, const int* __restrict__ pred, int G, int* __restrict__ flags) {
+    const int t = threadIdx.x;
+    if (t < G * G && (t / G != t % G) && matrix[t] > pred[t]) atomicOr(flags, kFlagMigSpill);   // (the same matrices on every rank: all raise it, or none)
+}
+__global__ __launch_bounds__(256) void k_let_slot_migrants(const Migrant* __restrict__ packed, const int* __restrict__ send_off,
+                                                           const int* __restrict__ pred, int G, int me, Migrant* __restrict__ slots) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= send_off[G]) return;
+    int dest = 0, slot0 = 0;
+    for (int r = 0; r < G; ++r) {
+        if (send_off[r] <= j) dest = r;
+    }
+    for (int r = 0; r < dest; ++r) slot0 += r == me ? 0 : pred[me * G + r];
+    const int k = j - send_off[dest];
+    if (dest != me && k < pred[me * G + dest]) slots[slot0 + k] = packed[j];
+}
+__global__ __launch_bounds__(256) void k_let_append_slots(float4* __restrict__ pos, float4* __restrict__ vel, float4* __restrict__ acc,
+                                                          int* __restrict__ ids, int* __restrict__ count, int cap,
+                                                          const Migrant* __restrict__ slots_in, const int* __restrict__ matrix,
+                                                          const int* __restrict__ pred, int G, int me, int* __restrict__ flags,
+                                                          int* __restrict__ new_count) {
+    if (*flags & kFlagMigSpill) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;   // position in the receive slots
+    const int n0 = *count;
+    int src = -1, slot0 = 0, before = 0, total = 0;
+    for (int r = 0, run = 0; r < G; ++r) {
+        const int p = r == me ? 0 : pred[r * G + me], a = r == me ? 0 : matrix[r * G + me];
+        if (src < 0 && j < run + p) { src = r; slot0 = run; before = total; }
+        run += p;
+        total += a;
+    }
+    if (j == 0) {
+        if (n0 + total > cap) atomicOr(flags, kFlagCapacity);
+        *new_count = min(cap, n0 + total);
+    }
+    if (src < 0) return;
+    const int k = j - slot0;
+    if (k >= matrix[src * G + me]) return;          // the padding of the message
+    const int d = n0 + before + k;
+    if (d >= cap) return;
+    const Migrant m = slots_in[j];
+    pos[d] = m.pos; vel[d] = m.vel; acc[d] = m.acc; ids[d] = m.id;
+}
+__global__ void k_let_report(const int* __restrict__ let_matrix, const int* __restrict__ mig_matrix, const int* __restrict__ offsets,
+                             const int* __restrict__ tree_info, const int* __restrict__ flags, int G, int* __restrict__ report) {
+    const int gg = G * G;
+    for (int t = threadIdx.x; t < gg; t += blockDim.x) { report[t] = let_matrix[t]; report[gg + t] = mig_matrix[t]; }
+    for (int t = threadIdx.x; t <= G; t += blockDim.x) report[2 * gg + t] = offsets[t];
+    if (threadIdx.x < 3) report[2 * gg + G + 1 + threadIdx.x] = tree_info[threadIdx.x];
+    if (threadIdx.x < 4) report[2 * gg + G + 4 + threadIdx.x] = flags[threadIdx.x];
 }
 
 // ---- what the other ranks need to know about this one before the second half of the build
@@ -510,7 +564,23 @@ void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float ce
 void launch_append(hipStream_t s, const Shard& sh, const Migrant* recv, int n_in, int G, int* flags, int* new_count, int* send_count) {
     hipLaunchKernelGGL(k_let_append, grid_for(n_in, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(), sh.seg_cap,
                        recv, n_in, flags, new_count);
-    hipLaunchKernelGGL(k_let_commit_count, dim3(1), dim3(64), 0, s, sh.own_count(), new_count, send_count, G, flags + 2);
+    hipLaunchKernelGGL(k_let_commit_count, dim3(1), dim3(64), 0, s, sh.own_count(), new_count, send_count, G, flags + 2, (const int*)nullptr);
+}
+void launch_spec_check(hipStream_t s, const int* matrix, const int* pred, int G, int* flags) {
+    hipLaunchKernelGGL(k_let_spec, dim3(1), dim3(256), 0, s, matrix, pred, G, flags);
+}
+void launch_slot_migrants(hipStream_t s, const Migrant* packed, int n_packed_upper, const int* send_off, const int* pred, int G, int me, Migrant* slots) {
+    if (n_packed_upper > 0) hipLaunchKernelGGL(k_let_slot_migrants, grid_for(n_packed_upper, 256), dim3(256), 0, s, packed, send_off, pred, G, me, slots);
+}
+void launch_append_slots(hipStream_t s, const Shard& sh, const Migrant* slots_in, int slots_in_upper, const int* matrix, const int* pred, int G, int me,
+                         int* flags, int* new_count, int* send_count) {
+    hipLaunchKernelGGL(k_let_append_slots, grid_for(slots_in_upper, 256), dim3(256), 0, s, sh.own_pos(), sh.vel, sh.acc, sh.ids, sh.own_count(), sh.seg_cap,
+                       slots_in, matrix, pred, G, me, flags, new_count);
+    hipLaunchKernelGGL(k_let_commit_count, dim3(1), dim3(64), 0, s, sh.own_count(), new_count, send_count, G, flags + 2, (const int*)flags);
+}
+void launch_report(hipStream_t s, const int* let_matrix, const int* mig_matrix, const int* offsets, const int* tree_info, const int* flags, int G,
+                   int* report) {
+    hipLaunchKernelGGL(k_let_report, dim3(1), dim3(256), 0, s, let_matrix, mig_matrix, offsets, tree_info, flags, G, report);
 }
 void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned long long* sorted_keys, const int* sorted_ids, int* box_ord,
                  unsigned long long* weight_sum, EndInfo* mine) {

@@ -68,12 +68,25 @@ struct State {
     LetRecord* d_let_recv = nullptr;
     size_t let_recv_cap = 0;
     int* d_let_matrix = nullptr;  // [G][G] counts (all-gathered rows)
-    int* h_pin = nullptr;         // pinned scratch [G*G + 64]
+    int* h_pin = nullptr;         // pinned scratch [report_ints(G) + 64]
+    int* d_report = nullptr;      // [report_ints(G)] what the host reads once per step (k_let_report)
+    // the migrant round with sizes posted ahead of the counts: pred = what every message is posted with, drawn from the
+    // last step's counts (the same on every rank); a step whose migrants do not fit makes the round again, exactly
+    bool have_pred = false;
+    std::vector<int> h_pred;      // [G * G]
+    int* d_pred = nullptr;        // [G * G]
+    int* h_pred_pin = nullptr;    // pinned staging of d_pred
+    Migrant* d_slot_out = nullptr;   // the packed emigrants again, one slot of pred[me][r] records per destination
+    size_t slot_out_cap = 0;
+    uint64_t spills = 0;          // steps that had to make their migrant round twice
+    uint64_t host_syncs = 0;      // host synchronisations inside passes (NbodyLetStats.host_syncs)
+    uint64_t node_array_peak = 0; // most node records this rank held at once: own slice + imports
     TreeDevWork work;
     NbodyLetStats st{};
     std::vector<int> recv_n;      // emulation / production: records received from each rank this pass
-    hipEvent_t ev[10] = {};       // begin/end of the five phases (nbody_set_profiling)
-    bool ev_made = false, ev_live = false;
+    hipEvent_t ev[2][10] = {};    // begin/end of the five phases (nbody_set_profiling), two sets: a step's are read during the next
+    bool ev_made = false, ev_live[2] = {false, false};
+    int ev_set = 0;               // the set the pass under way records into
 };
 
 namespace {
@@ -96,13 +109,23 @@ int fail(NbodyHandle* h, int code, const std::string& msg) { h->err = msg; retur
 struct PhaseTimer {
     NbodyHandle* h; State& s; int phase;
     PhaseTimer(NbodyHandle* h_, State& s_, int p) : h(h_), s(s_), phase(p) {
-        if (!h->profiling) { if (p == 0) s.ev_live = false; return; }
-        if (!s.ev_made) { for (hipEvent_t& e : s.ev) (void)hipEventCreate(&e); s.ev_made = true; }
-        if (p == 0) s.ev_live = true;
-        if (s.ev_live) (void)hipEventRecord(s.ev[2 * p], h->stream);
+        if (!h->profiling) { if (p == 0) s.ev_live[s.ev_set] = false; return; }
+        if (!s.ev_made) { for (auto& set : s.ev) for (hipEvent_t& e : set) (void)hipEventCreate(&e); s.ev_made = true; }
+        if (p == 0) s.ev_live[s.ev_set] = true;
+        if (s.ev_live[s.ev_set]) (void)hipEventRecord(s.ev[s.ev_set][2 * p], h->stream);
     }
-    ~PhaseTimer() { if (h->profiling && s.ev_live) (void)hipEventRecord(s.ev[2 * phase + 1], h->stream); }
+    ~PhaseTimer() { if (h->profiling && s.ev_live[s.ev_set]) (void)hipEventRecord(s.ev[s.ev_set][2 * phase + 1], h->stream); }
 };
+
+// adds up the five durations of a finished pass (the caller knows its events have completed)
+void collect_phase_times(State& s, int set) {
+    if (!s.ev_live[set]) return;
+    for (int p = 0; p < 5; ++p) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.ev[set][2 * p], s.ev[set][2 * p + 1]) == hipSuccess) s.st.phase_ms[p] += double(ms);
+    }
+    s.ev_live[set] = false;
+}
 
 unsigned long long host_key(const float* p, const float c[3], float width) {   // kernels_tree.hip k_tree_keys on the host
     float cx = c[0], cy = c[1], cz = c[2];
@@ -138,6 +161,12 @@ int ensure_node_buffers(NbodyHandle* h, State& s) {
         if ((rc = dev_alloc(h, &s.d_node_flags, size_t(want_local)))) return rc;
         s.let_stride = size_t(want_local);
         if ((rc = dev_alloc(h, &s.d_let_send, s.let_stride * size_t(s.G)))) return rc;
+        if (s.let_recv_cap < s.let_stride) {   // room for as many imports as a slice can have nodes: no allocation inside a step
+            if (s.d_let_recv) (void)hipFree(s.d_let_recv);
+            s.d_let_recv = nullptr; s.let_recv_cap = 0;
+            if ((rc = dev_alloc(h, &s.d_let_recv, s.let_stride))) return rc;
+            s.let_recv_cap = s.let_stride;
+        }
         s.local_cap = want_local;
     }
     const long long want_global = 4LL * (long long)h->cfg.capacity + 64LL * s.G + 64;
@@ -200,10 +229,12 @@ int phase0(NbodyHandle* h, State& s, float dt, bool drift) {
     return NBODY_OK;
 }
 
-int phase1(NbodyHandle* h, State& s) {
+// slots_in >= 0: the immigrants sit in receive slots of the predicted sizes (launch_append_slots); -1: packed, s.mig_in of them
+int phase1(NbodyHandle* h, State& s, int slots_in = -1) {
     Shard& sh = h->sh;
     PhaseTimer timer(h, s, 1);
-    launch_append(h->stream, sh, s.d_recv_mig, s.mig_in, s.G, s.d_flags, s.d_new_count, s.d_send_count);
+    if (slots_in >= 0) launch_append_slots(h->stream, sh, s.d_recv_mig, slots_in, s.d_mig_matrix, s.d_pred, s.G, s.me, s.d_flags, s.d_new_count, s.d_send_count);
+    else launch_append(h->stream, sh, s.d_recv_mig, s.mig_in, s.G, s.d_flags, s.d_new_count, s.d_send_count);
     // the host's bound of the own count: what was there before the retain + what arrived
     h->n_local = std::min<size_t>(size_t(sh.seg_cap), h->n_local + size_t(s.mig_in));
     if (tree_sort_keys(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->center, h->width, s.d_ws, s.ws_cap, s.d_tree_info, &s.work) != 0)
@@ -313,7 +344,11 @@ int create(NbodyHandle* h) {
     if ((rc = dev_alloc(h, &s.d_let_count, size_t(s.G)))) return rc;
     if ((rc = dev_alloc(h, &s.d_let_matrix, size_t(s.G) * s.G))) return rc;
     if ((rc = dev_alloc(h, &h->sh.ids, size_t(h->sh.seg_cap)))) return rc;
-    HIP_TRY(h, hipHostMalloc(&s.h_pin, (size_t(s.G) * s.G + 64) * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&s.h_pin, (size_t(report_ints(s.G)) + 64) * sizeof(int), hipHostMallocDefault));
+    if ((rc = dev_alloc(h, &s.d_report, size_t(report_ints(s.G))))) return rc;
+    if ((rc = dev_alloc(h, &s.d_pred, size_t(s.G) * s.G))) return rc;
+    HIP_TRY(h, hipHostMalloc(&s.h_pred_pin, size_t(s.G) * s.G * sizeof(int), hipHostMallocDefault));
+    s.h_pred.assign(size_t(s.G) * s.G, 0);
     h->sh.poison = s.d_flags;   // a raised flag stops every kernel that would change the state
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NBODY_OK;
@@ -325,12 +360,13 @@ void destroy(NbodyHandle* h) {
     void* dev[] = {s->d_bounds, s->d_bounds_scratch, s->d_weight_sum, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_send_off, s->d_mig_cursor, s->d_mig_matrix, s->d_dest_of, s->d_new_count, s->d_flags, s->d_box_ord,
                    s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_global, s->d_order, s->d_tree_info,
                    s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_send,
-                   s->d_let_recv, s->d_let_matrix, h->sh.ids};
+                   s->d_let_recv, s->d_let_matrix, h->sh.ids, s->d_report, s->d_pred, s->d_slot_out};
     for (void* p : dev) if (p) (void)hipFree(p);
     h->sh.ids = nullptr;
     h->sh.poison = nullptr;
     if (s->h_pin) (void)hipHostFree(s->h_pin);
-    if (s->ev_made) for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+    if (s->h_pred_pin) (void)hipHostFree(s->h_pred_pin);
+    if (s->ev_made) for (auto& set : s->ev) for (hipEvent_t e : set) (void)hipEventDestroy(e);
     delete s;
     h->let = nullptr;
 }
@@ -380,6 +416,7 @@ int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     HIP_TRY(h, hipMemsetAsync(sh.escaped, 0, sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d_send_count, 0, sizeof(int) * s.G, h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d_flags, 0, 4 * sizeof(int), h->stream));
+    s.have_pred = false;   // (the first step after an upload learns the migrant counts the slow way)
     h->n_local = m;
     h->seg_count_host[0] = int(m);
     h->h_counts[0] = int(m);
@@ -434,47 +471,78 @@ int count_global(NbodyHandle* h, size_t* n_out) {
 }
 
 int stats(NbodyHandle* h, NbodyLetStats* out) {
-    *out = h->let->st;
+    State& s = *h->let;
+    if (h->profiling && (s.ev_live[0] || s.ev_live[1])) {   // the last pass's phase events: wait for them
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        collect_phase_times(s, s.ev_set);
+        collect_phase_times(s, s.ev_set ^ 1);
+    }
+    s.st.host_syncs = s.host_syncs;
+    s.st.migrant_respills = s.spills;
+    s.st.node_array_peak_bytes = s.node_array_peak * sizeof(LetRecord);
+    s.st.node_array_bytes = uint64_t(std::max(0, s.global_cap)) * sizeof(LetRecord);
+    *out = s.st;
     return NBODY_OK;
 }
 
 int reset_stats(NbodyHandle* h) {
-    h->let->st = NbodyLetStats{};
-    HIP_TRY(h, hipMemsetAsync(h->let->d_flags + 2, 0, sizeof(int), h->stream));
+    State& s = *h->let;
+    s.st = NbodyLetStats{};
+    s.host_syncs = 0; s.spills = 0; s.node_array_peak = 0; s.migrated_seen = 0;
+    s.ev_live[0] = s.ev_live[1] = false;
+    HIP_TRY(h, hipMemsetAsync(s.d_flags + 2, 0, sizeof(int), h->stream));
     return NBODY_OK;
 }
 
-// bookkeeping after a pass: read the small numbers back (the pass is over: the caller synchronises anyway)
-static int account(NbodyHandle* h, State& s) {
-    HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_let_count, sizeof(int) * s.G, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_pin + 16, s.d_offsets, sizeof(int) * (s.G + 1), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_pin + 40, s.d_tree_info, sizeof(int) * 3, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_pin + 44, s.d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    uint64_t sent = 0;
-    for (int r = 0; r < s.G; ++r) sent += uint64_t(std::max(0, s.h_pin[r]));
+// bookkeeping after a pass, from the numbers of the step's report block (rep = h_pin after the copy of d_report)
+static void account_from(NbodyHandle* h, State& s, const int* rep) {
+    const int G = s.G, gg = G * G;
+    const int* let_m = rep;
+    const int* offsets = rep + 2 * gg;
+    const int* tree_info = rep + 2 * gg + G + 1;
+    const int* flags = rep + 2 * gg + G + 4;
+    uint64_t sent = 0, rec = 0;
+    if (h->comm_ready)
+        for (int r = 0; r < G; ++r) {
+            if (r == s.me) continue;
+            sent += uint64_t(std::min<long long>(std::max(0, let_m[s.me * G + r]), (long long)s.let_stride));
+            rec += uint64_t(std::min<long long>(std::max(0, let_m[r * G + s.me]), (long long)s.let_stride));
+        }
     s.st.nodes_sent += sent;
-    s.st.nodes_local += uint64_t(std::max(0, s.h_pin[40]));
-    s.st.nodes_global += uint64_t(std::max(0, s.h_pin[16 + s.G]));
-    h->stats.tree_nodes = uint64_t(std::max(1, s.h_pin[16 + s.G]));   // (an empty world: the reference's empty root, barnes_hut.rs:145)
-    h->n_local = size_t(std::max(0, s.h_pin[42]));   // the live own count (bodies in the local build)
+    s.st.nodes_received += rec;
+    s.st.nodes_local += uint64_t(std::max(0, tree_info[0]));
+    s.st.nodes_global += uint64_t(std::max(0, offsets[G]));
+    s.node_array_peak = std::max<uint64_t>(s.node_array_peak, uint64_t(std::max(0, tree_info[0])) + rec);
+    h->stats.tree_nodes = uint64_t(std::max(1, offsets[G]));   // (an empty world: the reference's empty root, barnes_hut.rs:145)
+    h->n_local = size_t(std::max(0, tree_info[2]));            // the live own count (bodies in the local build)
     h->seg_count_host[0] = int(h->n_local);
     h->count_dirty = false;
-    const uint64_t partners = uint64_t(std::max(0, s.G - 1));
-    const uint64_t migrated_now = uint64_t(std::max(0, s.h_pin[44]));
+    const uint64_t partners = uint64_t(std::max(0, G - 1));
+    const uint64_t migrated_now = uint64_t(std::max(0, flags[2]));
     s.st.bytes_sent += sent * sizeof(LetRecord) + (migrated_now - std::min(migrated_now, s.migrated_seen)) * sizeof(Migrant) +
-                       partners * (2 * uint64_t(s.G) * sizeof(int) + sizeof(EndInfo) + sizeof(RoundB));
+                       partners * (2 * uint64_t(G) * sizeof(int) + sizeof(EndInfo) + sizeof(RoundB));
     s.migrated_seen = migrated_now;
-    s.st.bytes_allgather_equivalent += partners * uint64_t(std::max(0, s.h_pin[42])) * 16ull;
-    uint64_t rec = 0;
-    for (int n : s.recv_n) rec += uint64_t(n);
+    s.st.bytes_allgather_equivalent += partners * uint64_t(std::max(0, tree_info[2])) * 16ull;
+    s.st.bodies_migrated = migrated_now;
+}
+
+// the emulation's bookkeeping (debug_phase): the same numbers, fetched with a synchronisation of their own
+static int account(NbodyHandle* h, State& s) {
+    launch_report(h->stream, s.d_let_matrix, s.d_mig_matrix, s.d_offsets, s.d_tree_info, s.d_flags, s.G, s.d_report);
+    HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_report, sizeof(int) * report_ints(s.G), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_pin + report_ints(s.G), s.d_let_count, sizeof(int) * s.G, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const bool was = h->comm_ready;
+    h->comm_ready = false;   // (the emulation counts what debug_exchange moved: recv_n; exports from the rank's own counts)
+    account_from(h, s, s.h_pin);
+    h->comm_ready = was;
+    uint64_t sent = 0, rec = 0;
+    for (int r = 0; r < s.G; ++r) { sent += uint64_t(std::max(0, s.h_pin[report_ints(s.G) + r])); rec += uint64_t(s.recv_n[r]); }
+    s.st.nodes_sent += sent;
     s.st.nodes_received += rec;
-    s.st.bodies_migrated = uint64_t(std::max(0, s.h_pin[44]));
-    if (h->profiling && s.ev_live)
-        for (int p = 0; p < 5; ++p) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s.ev[2 * p], s.ev[2 * p + 1]) == hipSuccess) s.st.phase_ms[p] += double(ms);
-        }
+    s.st.bytes_sent += sent * sizeof(LetRecord);
+    s.node_array_peak = std::max<uint64_t>(s.node_array_peak, uint64_t(std::max(0, s.h_pin[2 * s.G * s.G + s.G + 1])) + rec);
+    if (h->profiling) collect_phase_times(s, s.ev_set);
     return NBODY_OK;
 }
 
@@ -499,81 +567,173 @@ size_t exchange_layout(const int* m, int G, int me, long long clamp, bool packed
     return in_run;
 }
 
-// ---- production: the exchanges through the handle's transport (RCCL; or the one-device transport), on the handle's stream
+static int flags_to_error(NbodyHandle* h, State& s, int f) {
+    if (!f) return NBODY_OK;
+    const std::string who = " (flag word " + std::to_string(f) + ")";
+    if (f & kFlagDeep) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 42 levels (coincident?)" + who);
+    if (f & kFlagCapacity) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: a rank's capacity is exhausted by immigrants");
+    if (f & (kFlagNodeCap | kFlagNodeCapLocal)) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: node array too small");
+    return fail(h, NBODY_ERR_INVALID, "spatial shards: the device raised flag " + std::to_string(f));
+}
+
+// one grouped send/recv round of records of `rec` bytes: to rank r n_out[r] records from send + out_at[r], from rank r n_in[r] into recv + in_at[r]
+static int variable_round(NbodyHandle* h, State& s, const char* send, char* recv, size_t rec, const size_t* out_at, const size_t* n_out, const size_t* in_at,
+                          const size_t* n_in) {
+    TP_TRY(h, h->tp->group_begin());
+    for (int r = 0; r < s.G; ++r) {
+        if (n_out[r] > 0) TP_TRY(h, h->tp->send(send + out_at[r] * rec, n_out[r] * rec, r, h->stream));
+        if (n_in[r] > 0) TP_TRY(h, h->tp->recv(recv + in_at[r] * rec, n_in[r] * rec, r, h->stream));
+    }
+    TP_TRY(h, h->tp->group_end());
+    return NBODY_OK;
+}
+
+// exchange 0 with the sizes the host knows exactly (m = the migrant count matrix on the host)
+static int migrants_exact(NbodyHandle* h, State& s, const int* m) {
+    size_t out_at[kMaxRanks], n_out[kMaxRanks], in_at[kMaxRanks], n_in[kMaxRanks];
+    const size_t total_in = exchange_layout(m, s.G, s.me, (long long)h->sh.seg_cap, true, 0, out_at, n_out, in_at, n_in);
+    int rc = ensure_mig_recv(h, s, total_in, 0);
+    if (rc) return rc;
+    rc = variable_round(h, s, reinterpret_cast<const char*>(s.d_send_mig), reinterpret_cast<char*>(s.d_recv_mig), sizeof(Migrant), out_at, n_out, in_at, n_in);
+    if (rc) return rc;
+    s.mig_in = int(total_in);
+    return NBODY_OK;
+}
+
+// what the next step posts its migrant messages with: twice the last count and a little, the same on every rank
+static int draw_prediction(NbodyHandle* h, State& s, const int* mig_m) {
+    const int G = s.G;
+    size_t out_need = 0, in_need = 0;
+    for (int a = 0; a < G; ++a)
+        for (int b = 0; b < G; ++b) {
+            const int p = a == b ? 0 : int(std::min<long long>(2LL * std::max(0, mig_m[a * G + b]) + 32, (long long)h->sh.seg_cap));
+            s.h_pred[size_t(a) * G + b] = p;
+            if (a == s.me) out_need += size_t(p);
+            if (b == s.me) in_need += size_t(p);
+        }
+    // (the host is synchronised here: growing a buffer costs nothing but the call)
+    if (out_need > s.slot_out_cap) {
+        if (s.d_slot_out) (void)hipFree(s.d_slot_out);
+        s.d_slot_out = nullptr; s.slot_out_cap = 0;
+        const size_t cap = out_need + out_need / 2 + 1024;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_slot_out), cap * sizeof(Migrant)));
+        s.slot_out_cap = cap;
+    }
+    int rc = ensure_mig_recv(h, s, in_need, 0);
+    if (rc) return rc;
+    std::memcpy(s.h_pred_pin, s.h_pred.data(), sizeof(int) * size_t(G) * G);
+    HIP_TRY(h, hipMemcpyAsync(s.d_pred, s.h_pred_pin, sizeof(int) * size_t(G) * G, hipMemcpyHostToDevice, h->stream));   // (read by the NEXT pass; the staging is rewritten only after that pass's own synchronisation)
+    s.have_pred = true;
+    return NBODY_OK;
+}
+
+// ---- production: the exchanges through the handle's transport (RCCL; or the one-device transport), on the handle's stream.
+// ONE host synchronisation per pass in the steady state: after phase 3 the host reads one block (k_let_report: both count
+// matrices, the slice offsets, the build's numbers, the flags) -- it needs the export counts there to post the node round --
+// and does the pass's bookkeeping and error check from it.  The migrant round does not wait for its counts: its messages are
+// posted with sizes drawn from the previous step's counts (draw_prediction); if some pair has more migrants than that, every
+// rank sees it in the all-gathered matrix (kFlagMigSpill), nothing is committed, and after the synchronisation the round is
+// made again with the exact sizes and phases 1-3 are repeated (NbodyLetStats.migrant_respills counts such steps).
 static int pass(NbodyHandle* h, float dt, bool is_step) {
     State& s = *h->let;
-    if (s.G > 1 && !h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    const int G = s.G, gg = G * G;
+    if (G > 1 && !h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
     const bool comm = h->comm_ready;   // (a world of one WITH a communicator still runs every collective: the 1-rank rehearsal)
     size_t out_at[kMaxRanks], n_out[kMaxRanks], in_at[kMaxRanks], n_in[kMaxRanks];
+    if (h->profiling) {   // the previous pass's phase events have all completed by the time this pass synchronises; read them now if they have
+        const int prev = s.ev_set ^ 1;
+        if (s.ev_live[prev] && hipEventQuery(s.ev[prev][9]) == hipSuccess) collect_phase_times(s, prev);
+    }
     int rc = phase0(h, s, dt, is_step);
     if (rc) return rc;
-    if (comm) {   // exchange 0: the counts first (row r = what rank r sends to everybody), then the migrants themselves
-        HIP_TRY(h, hipMemcpyAsync(s.d_mig_matrix + size_t(s.me) * s.G, s.d_send_count, sizeof(int) * s.G, hipMemcpyDeviceToDevice, h->stream));
-        TP_TRY(h, h->tp->all_gather(s.d_mig_matrix, sizeof(int) * size_t(s.G), h->stream));
-        HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_mig_matrix, sizeof(int) * s.G * s.G, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        const size_t total_in = exchange_layout(s.h_pin, s.G, s.me, (long long)h->sh.seg_cap, true, 0, out_at, n_out, in_at, n_in);
-        rc = ensure_mig_recv(h, s, total_in, 0);
-        if (rc) return rc;
-        TP_TRY(h, h->tp->group_begin());
-        for (int r = 0; r < s.G; ++r) {
-            if (n_out[r] > 0) TP_TRY(h, h->tp->send(s.d_send_mig + out_at[r], n_out[r] * sizeof(Migrant), r, h->stream));
-            if (n_in[r] > 0) TP_TRY(h, h->tp->recv(s.d_recv_mig + in_at[r], n_in[r] * sizeof(Migrant), r, h->stream));
+    int slots_in = -1;
+    if (comm) {   // exchange 0: the counts (row r = what rank r sends to everybody), then the migrants themselves
+        HIP_TRY(h, hipMemcpyAsync(s.d_mig_matrix + size_t(s.me) * G, s.d_send_count, sizeof(int) * G, hipMemcpyDeviceToDevice, h->stream));
+        TP_TRY(h, h->tp->all_gather(s.d_mig_matrix, sizeof(int) * size_t(G), h->stream));
+        if (s.have_pred) {
+            launch_spec_check(h->stream, s.d_mig_matrix, s.d_pred, G, s.d_flags);
+            launch_slot_migrants(h->stream, s.d_send_mig, int(std::min<size_t>(h->n_local, size_t(h->sh.seg_cap))), s.d_send_off, s.d_pred, G, s.me, s.d_slot_out);
+            const size_t total_in = exchange_layout(s.h_pred.data(), G, s.me, (long long)h->sh.seg_cap, true, 0, out_at, n_out, in_at, n_in);
+            rc = variable_round(h, s, reinterpret_cast<const char*>(s.d_slot_out), reinterpret_cast<char*>(s.d_recv_mig), sizeof(Migrant), out_at, n_out, in_at, n_in);
+            if (rc) return rc;
+            slots_in = int(total_in);
+            s.mig_in = int(total_in);   // (the host's bound of what may arrive)
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_mig_matrix, sizeof(int) * gg, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            s.host_syncs += 1;
+            rc = migrants_exact(h, s, s.h_pin);
+            if (rc) return rc;
         }
-        TP_TRY(h, h->tp->group_end());
-        s.mig_in = int(total_in);
     }
-    rc = phase1(h, s);
-    if (rc) return rc;
-    if (comm) TP_TRY(h, h->tp->all_gather(s.d_ends, sizeof(EndInfo), h->stream));   // exchange 1
-    rc = phase2(h, s);
-    if (rc) return rc;
-    if (comm) TP_TRY(h, h->tp->all_gather(s.d_rb, sizeof(RoundB), h->stream));      // exchange 2
-    rc = phase3(h, s);
-    if (rc) return rc;
+    const size_t n_before = h->n_local;   // (phase 1 raises the host's bound by what may arrive: a repeated round starts from here again)
+    const int* rep = s.h_pin;
+    for (int attempt = 0;; ++attempt) {
+        rc = phase1(h, s, slots_in);
+        if (rc) return rc;
+        if (comm) TP_TRY(h, h->tp->all_gather(s.d_ends, sizeof(EndInfo), h->stream));   // exchange 1
+        rc = phase2(h, s);
+        if (rc) return rc;
+        if (comm) TP_TRY(h, h->tp->all_gather(s.d_rb, sizeof(RoundB), h->stream));      // exchange 2
+        rc = phase3(h, s);
+        if (rc) return rc;
+        if (comm) {   // exchange 3, first half: the export counts (row r of the matrix = what rank r sends to everybody)
+            HIP_TRY(h, hipMemcpyAsync(s.d_let_matrix + size_t(s.me) * G, s.d_let_count, sizeof(int) * G, hipMemcpyDeviceToDevice, h->stream));
+            TP_TRY(h, h->tp->all_gather(s.d_let_matrix, sizeof(int) * size_t(G), h->stream));
+        }
+        launch_report(h->stream, s.d_let_matrix, s.d_mig_matrix, s.d_offsets, s.d_tree_info, s.d_flags, G, s.d_report);
+        HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_report, sizeof(int) * report_ints(G), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));   // the one synchronisation of the pass
+        s.host_syncs += 1;
+        const int f = rep[2 * gg + G + 4];
+        if (!(f & kFlagMigSpill)) break;
+        // more migrants than their messages were posted for: every rank is here (they all saw the same matrices).  Nothing was
+        // committed; the emigrants are still packed in d_send_mig: the round again, exactly, then phases 1-3 again.
+        if ((f & ~kFlagMigSpill) || attempt > 0) return flags_to_error(h, s, (f & ~kFlagMigSpill) ? (f & ~kFlagMigSpill) : f);
+        s.spills += 1;
+        HIP_TRY(h, hipMemsetAsync(s.d_flags, 0, sizeof(int), h->stream));
+        h->n_local = n_before;
+        std::vector<int> mig(rep + gg, rep + 2 * gg);   // (h_pin is about to be reused)
+        rc = migrants_exact(h, s, mig.data());
+        if (rc) return rc;
+        slots_in = -1;
+    }
+    {
+        const int f = rep[2 * gg + G + 4];
+        if (f) return flags_to_error(h, s, f);
+    }
+    if (h->tp) { rc = h->tp->check(); if (rc) return fail(h, rc, h->tp->error()); }
+    account_from(h, s, rep);
     std::fill(s.recv_n.begin(), s.recv_n.end(), 0);
-    if (comm) {   // exchange 3: the counts first (row r of the matrix = what rank r sends to everybody), then the records
-        HIP_TRY(h, hipMemcpyAsync(s.d_let_matrix + size_t(s.me) * s.G, s.d_let_count, sizeof(int) * s.G, hipMemcpyDeviceToDevice, h->stream));
-        TP_TRY(h, h->tp->all_gather(s.d_let_matrix, sizeof(int) * size_t(s.G), h->stream));
-        HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_let_matrix, sizeof(int) * s.G * s.G, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        for (int a = 0; a < s.G; ++a)
-            for (int b = 0; b < s.G; ++b)
-                if (a != b && size_t(std::max(0, s.h_pin[a * s.G + b])) > s.let_stride)   // (every rank sees the same matrix: all of them stop here)
-                    return fail(h, NBODY_ERR_CAPACITY, "spatial shards: export list overflow (rank " + std::to_string(a) + " has " + std::to_string(s.h_pin[a * s.G + b]) +
+    if (comm) {
+        for (int a = 0; a < G; ++a)
+            for (int b = 0; b < G; ++b)
+                if (a != b && size_t(std::max(0, rep[a * G + b])) > s.let_stride)   // (every rank sees the same matrix: all of them stop here)
+                    return fail(h, NBODY_ERR_CAPACITY, "spatial shards: export list overflow (rank " + std::to_string(a) + " has " + std::to_string(rep[a * G + b]) +
                                                            " nodes for rank " + std::to_string(b) + ", its list holds " + std::to_string(s.let_stride) + ")");
-        const size_t total_in = exchange_layout(s.h_pin, s.G, s.me, (long long)s.let_stride, false, s.let_stride, out_at, n_out, in_at, n_in);
-        for (int r = 0; r < s.G; ++r) s.recv_n[r] = int(n_in[r]);
-        if (total_in > s.let_recv_cap) {
+        const size_t total_in = exchange_layout(rep, G, s.me, (long long)s.let_stride, false, s.let_stride, out_at, n_out, in_at, n_in);
+        for (int r = 0; r < G; ++r) s.recv_n[r] = int(n_in[r]);
+        if (total_in > s.let_recv_cap) {   // (sized for a slice's worth at creation: only a rank that imports more than it can own gets here)
             if (s.d_let_recv) (void)hipFree(s.d_let_recv);
             s.d_let_recv = nullptr; s.let_recv_cap = 0;
             HIP_TRY(h, hipMalloc(&s.d_let_recv, (total_in + total_in / 4 + 1024) * sizeof(LetRecord)));
             s.let_recv_cap = total_in + total_in / 4 + 1024;
         }
-        TP_TRY(h, h->tp->group_begin());
-        for (int r = 0; r < s.G; ++r) {
-            if (n_out[r] > 0) TP_TRY(h, h->tp->send(s.d_let_send + out_at[r], n_out[r] * sizeof(LetRecord), r, h->stream));
-            if (n_in[r] > 0) TP_TRY(h, h->tp->recv(s.d_let_recv + in_at[r], n_in[r] * sizeof(LetRecord), r, h->stream));
-        }
-        TP_TRY(h, h->tp->group_end());
+        rc = draw_prediction(h, s, rep + gg);   // (before h_pin is reused; uploads next step's sizes)
+        if (rc) return rc;
+        rc = variable_round(h, s, reinterpret_cast<const char*>(s.d_let_send), reinterpret_cast<char*>(s.d_let_recv), sizeof(LetRecord), out_at, n_out, in_at, n_in);
+        if (rc) return rc;
         if (total_in > 0) launch_scatter(h->stream, s.d_let_recv, int(total_in), s.d_global, s.global_cap);
     }
     rc = phase4(h, s, dt, is_step);
     if (rc) return rc;
-    return account(h, s);
+    s.ev_set ^= 1;   // (the next pass records into the other set; this one's are read once they have completed)
+    return NBODY_OK;
 }
 
-int step(NbodyHandle* h, float dt) {
-    int rc = pass(h, dt, true);
-    if (rc) return rc;
-    return check_flags(h);
-}
+int step(NbodyHandle* h, float dt) { return pass(h, dt, true); }
 
-int update_forces(NbodyHandle* h) {
-    int rc = pass(h, 0.f, false);
-    if (rc) return rc;
-    return check_flags(h);
-}
+int update_forces(NbodyHandle* h) { return pass(h, 0.f, false); }
 
 // ---- one-process emulation: phases and exchanges driven from outside
 int debug_phase(NbodyHandle* h, int phase, float dt) {

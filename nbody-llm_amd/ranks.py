@@ -112,7 +112,8 @@ def _rank_main(cfg: dict, rank: int, failed: list) -> None:
                 "node_visits": int(st.node_visits), "tree_nodes": int(st.tree_nodes), "local_range": list(sim.local_range())}
         if cfg["sim"].get("shard", "index") == "spatial":
             ls = sim.let_stats()
-            meta["let"] = {k: int(getattr(ls, k)) for k in ("steps", "bodies_migrated", "nodes_local", "nodes_global", "nodes_sent", "nodes_received", "bytes_sent")}
+            meta["let"] = {k: int(getattr(ls, k)) for k in ("steps", "bodies_migrated", "nodes_local", "nodes_global", "nodes_sent", "nodes_received", "bytes_sent", "host_syncs",
+                                                                "migrant_respills", "node_array_peak_bytes", "node_array_bytes")}
         rdzv.barrier()   # nobody leaves (and takes its window away) while a peer may still be inside an exchange
         sim.close()
         np.savez(os.path.join(out, f"rank{rank}.npz"), **arrays)

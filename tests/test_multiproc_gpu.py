@@ -148,6 +148,32 @@ def test_barnes_hut_spatial_ranks_with_migration(gpu, tmp_path, G, n, box_w, lea
         assert sum(r["let"]["nodes_sent"] for r in res) == sum(r["let"]["nodes_received"] for r in res) > 0
         if box_w < 10:
             assert sum(r["let"]["bodies_migrated"] for r in res) > 0
+        for r in res:   # one host synchronisation per step (+ one more in the first, which learns the migrant counts the slow way, and per repeated migrant round)
+            assert r["let"]["steps"] == 6 and r["let"]["host_syncs"] == 6 + 1 + r["let"]["migrant_respills"], r["let"]
+            assert 0 < r["let"]["node_array_peak_bytes"] <= r["let"]["node_array_bytes"]
+
+
+def test_spatial_step_repeats_its_migrant_round_when_the_posted_sizes_do_not_hold(gpu, tmp_path):
+    """The migrant messages of a step are posted with sizes drawn from the previous step's counts.  Two quiet steps, then
+    one that moves every body a long way: far more bodies change ranks than predicted, every rank sees it in the
+    all-gathered count matrix, nothing is committed, and the round is made again with the exact sizes -- the world still
+    equals the one-handle run."""
+    nb = gpu
+    from nbody_llm_amd import ranks
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-4, theta2=0.25)
+    cfg = world_cfg(tmp_path, 3, dict(method="bh", math="fast", shard="spatial"), dict(n=6000, seed=66), sd,
+                    [["step_by", 1e-4], ["step_by", 1e-4], ["step_by", 0.4], ["step_by", 1e-4], ["step_by", 1e-4]])
+    res = launch(cfg, 3)
+    got = ranks.gather_world(res)
+    ref, s1 = single(nb, cfg, tree="device")
+    assert len(got) == len(ref) == 6000
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 5e-6
+    assert_same_up_to_flips(got["acceleration"], ref["acceleration"], 1e-5)
+    assert all(r["let"]["migrant_respills"] >= 1 for r in res), [r["let"] for r in res]
+    assert len({r["let"]["migrant_respills"] for r in res}) == 1          # every rank repeated the same rounds
+    assert sum(r["let"]["bodies_migrated"] for r in res) > 500
+    for r in res:
+        assert r["let"]["host_syncs"] == 5 + 1 + r["let"]["migrant_respills"]
 
 
 def test_ranks_created_unlike_fail_at_comm_init_instead_of_hanging(gpu, tmp_path):
