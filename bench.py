@@ -58,8 +58,12 @@ PARITY = {
                     "over 1 000 steps at N = 65 536 (absolute: a CPU step takes ~9 s there), and within 1e-5 of the CPU oracle "
                     "trajectory's drift at N = 8 192)",
     ("bf", "strict"): "strict math: bit-exact vs the oracle (tests/test_bf_gpu.py, tests/test_golden.py)",
-    ("bh", "fast"): "fast math: node counts exact, acc <= 1e-5 of max|acc| vs the oracle (tests/test_bh_gpu.py); device tree: "
-                    "structure bit-equal, counts within 1e-3 (tests/test_bh_device_tree_gpu.py)",
+    ("bh", "fast"): "fast math, a tolerance and (device tree) a distribution, not bit-exactness.  Host-built tree: node counts equal the oracle's, "
+                    "every body within 1e-4 of its OWN |a| (median 1e-7, 99.9th percentile 1e-6 at N = 65 536; max 4.8e-6; 3.7e-5 at 2^20).  "
+                    "Device-built tree (what NBODY_TREE_AUTO picks for fast math): same cells, centres of mass to the reference fold's own rounding, "
+                    "so an opening test on its threshold can flip: accepted nodes within 1e-6 of the oracle's count, same median, 0 bodies beyond "
+                    "1e-5 of their own |a| at N = 65 536 (max 8.9e-6), 217 of 2^20 beyond 1e-5 (max 4.9e-4 of own |a|, 2e-4 of max|a|) "
+                    "(tests/test_bh_parity_evidence_gpu.py, both leaf rules; tests/test_bh_gpu.py, tests/test_bh_device_tree_gpu.py)",
     ("bh", "strict"): "strict math: accelerations and trajectories bit-exact vs the oracle (tests/test_bh_gpu.py, tests/test_large_gpu.py)",
 }
 
