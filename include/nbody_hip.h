@@ -184,6 +184,18 @@ int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* sk
 int nbody_tree_export_f64(NbodyHandle* h, double* com_mass, double* width, int32_t* skip, size_t cap, size_t* n_nodes); /* f64 handles */
 const char* nbody_last_error(const NbodyHandle* h); /* h may be NULL: last create/clone error */
 
+/* ---- launch-shape and scheme knobs of one handle (no reference counterpart) --------------------------------- */
+/* Per handle; the library exports no mutable globals.  Names (csrc/kernels.h struct Tuning): cross_sym, sym_packed,
+ * bf_fast_variant, sym_wpb, sym_rounds, sym_reduce_split, cross_slots, cross_ipt, cross_wpb, bh_walk_split, bh_walk_order,
+ * bh_reduce_split, tree_max_tie; the environment switches NBODY_CROSS_SYM, NBODY_SYM_PACKED, NBODY_BF_VARIANT, NBODY_SYM_WPB
+ * and NBODY_BH_SPLIT preset them at nbody_create.  cross_sym, sym_packed and bf_fast_variant are part of what the ranks of a
+ * world agree on at nbody_comm_init and cannot change afterwards.  bh_walk_variant, bh_walk_lds_block, bh_hot_cap,
+ * bh_walk_debug and sym_debug select experimental walks and in-kernel stamps that only the tuning build carries
+ * (libnbody_hip_tuning.so, `make -C nbody-llm_amd/csrc tuning`): the release library refuses them. */
+int nbody_set_tuning(NbodyHandle* h, const char* name, int value);
+int nbody_get_tuning(const NbodyHandle* h, const char* name, int* value);
+int nbody_is_tuning_build(void);
+
 /* ---- multi-GPU (no reference counterpart) ------------------------ */
 #define NBODY_COMM_ID_BYTES 128
 /* rank 0 calls nbody_comm_unique_id and ships the bytes to the other ranks out of band; every

@@ -17,7 +17,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbody_hip.so")
+# NBODY_HIP_LIBRARY: another build of the same ABI -- libnbody_hip_tuning.so carries the experimental walks and the
+# in-kernel stamps the release library leaves out (make -C nbody-llm_amd/csrc tuning; __graft_entry__.load_package(tuning=True))
+LIB_PATH = os.environ.get("NBODY_HIP_LIBRARY") or os.path.join(_HERE, "libnbody_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -25,7 +27,7 @@ if not os.path.exists(LIB_PATH):
         "there is no Python/CPU fallback for the HIP engine"
     )
 
-lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)   # (two builds of the library may live in one process: nothing is resolved across them)
 
 # ---- constants (include/nbody_hip.h) ----------------------------------------------------------
 NBODY_OK = 0
@@ -70,6 +72,7 @@ DECLARED_SYMBOLS = [
     "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
     "nbody_debug_let_bounds", "nbody_debug_let_set_balance",
     "nbody_comm_local_id", "nbody_comm_transport", "nbody_host_exchange_layout",
+    "nbody_set_tuning", "nbody_get_tuning", "nbody_is_tuning_build",
 ]
 
 
@@ -165,8 +168,34 @@ _sig("nbody_debug_let_set_prune", _i, _H, _i)
 _sig("nbody_debug_let_bounds", _i, _H, C.c_void_p)
 _sig("nbody_debug_let_set_balance", _i, _H, _i)
 _sig("nbody_host_exchange_layout", _i, C.c_void_p, _i, _i, C.c_longlong, _i, _sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_sz))
+_sig("nbody_set_tuning", _i, _H, C.c_char_p, _i)
+_sig("nbody_get_tuning", _i, _H, C.c_char_p, C.POINTER(_i))
+_sig("nbody_is_tuning_build", _i)
 _sig("nbody_abi_version", _i)
 _sig("nbody_device_count", _i)
+
+
+#: knobs every Simulation created from here on starts with (host-side convenience of this mirror; the library itself
+#: keeps its knobs per handle): `with tuning_defaults(bh_walk_split=4): ...`
+_default_tuning: dict = {}
+
+
+class tuning_defaults:
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        self.saved = dict(_default_tuning)
+        _default_tuning.update(self.knobs)
+        return self
+
+    def __exit__(self, *a):
+        _default_tuning.clear()
+        _default_tuning.update(self.saved)
+
+
+def is_tuning_build() -> bool:
+    return bool(lib.nbody_is_tuning_build())
 
 
 class NbodyError(RuntimeError):
@@ -250,7 +279,7 @@ class Simulation:
     def __init__(self, points: np.ndarray, center=(0.0, 0.0, 0.0), width: float = 1.0, *, method: int = BRUTE_FORCE,
                  math_mode: int = STRICT, capacity: int | None = None, device: int = -1, rank: int = 0,
                  world_size: int = 1, host_threads: int = 0, tree_build: int = TREE_AUTO, leaf_mode: int = LEAF_REFERENCE,
-                 f64: bool | None = None, shard_mode: int = SHARD_INDEX, _handle=None, _f64: bool = False):
+                 f64: bool | None = None, shard_mode: int = SHARD_INDEX, tuning: dict | None = None, _handle=None, _f64: bool = False):
         self._h = _H()
         self.f64 = bool(_f64)
         self.rank, self.world_size = int(rank), int(world_size)
@@ -268,6 +297,8 @@ class Simulation:
         if rc:
             self._h = _H()
             raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
+        for name, value in {**_default_tuning, **(tuning or {})}.items():
+            self.set_tuning(name, value)
         self.set_bounds(center, width)
         self._check(lib.nbody_upload(self._h, points.ctypes.data, points.shape[0], self.dtype.itemsize))
 
@@ -440,6 +471,15 @@ class Simulation:
     def comm_init(self, id_bytes: bytes):
         buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
         self._check(lib.nbody_comm_init(self._h, buf))
+
+    def set_tuning(self, name: str, value: int):
+        """One launch-shape / scheme knob of this handle (include/nbody_hip.h nbody_set_tuning)."""
+        self._check(lib.nbody_set_tuning(self._h, name.encode(), int(value)))
+
+    def get_tuning(self, name: str) -> int:
+        v = C.c_int(0)
+        self._check(lib.nbody_get_tuning(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def comm_transport(self) -> str:
         buf = C.create_string_buffer(16)

@@ -6,6 +6,35 @@
 
 namespace nbody {
 
+// Launch-shape and scheme knobs of ONE handle (NbodyHandle::tune): set at nbody_create from the documented NBODY_*
+// environment switches, changed with nbody_set_tuning.  The launchers read the knobs of the handle the calling thread
+// is serving (tuning(); every C entry point binds them), so two handles -- or two rank threads of one process -- never
+// see each other's settings, and the library exports no mutable tuning globals.
+struct Tuning {
+    int cross_sym = 1;          // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided  [NBODY_CROSS_SYM]
+    int sym_packed = 1;         // 1: packed-fp32 pair evaluation (pair_evals_pk), 0: scalar                                       [NBODY_SYM_PACKED]
+    int bf_fast_variant = 0;    // 0: symmetric kernels where they apply, 1..: the LDS-tiled one-sided forms (kernels_bf.hip)       [NBODY_BF_VARIANT]
+    int sym_wpb = 12;           // k_bf_sym: waves per workgroup: 16, 12 or 8                                                       [NBODY_SYM_WPB]
+    int sym_rounds = 1;         // k_bf_sym: rounds of workgroups per CU
+    int sym_reduce_split = 1;   // plane reduction: 1 = several waves per 64 bodies, 0 = one thread per body
+    int cross_slots = 3072;     // k_bf_cross: waves the chunk visits are dealt to
+    int cross_ipt = 0;          // k_bf_cross: resident bodies per lane: 0 = by rule, 4, 8
+    int cross_wpb = 4;          // k_bf_cross: waves per workgroup: 4, 8, 12
+    int bh_walk_split = 0;      // node-range segments per body group: 0 = automatic                                                [NBODY_BH_SPLIT]
+    int bh_walk_order = 1;      // 1: a group's segments are dispatched nearest-first (heaviest first), 0: in index order
+    int bh_reduce_split = 1;    // 1: four waves per 64 bodies in the walk's plane reduction when there are >= 8 segments
+    int tree_max_tie = 64;      // device build: largest run of equal 63-bit keys that gets second keys (beyond: "too deep")
+    // the following select code that only the tuning build carries (make -C csrc tuning: -DNBODY_TUNING); the release
+    // library refuses any value but the default
+    int bh_walk_variant = 0;    // 1 wave-cooperative, 2 two lanes per body, 3 hot records in LDS, 4 cooperative window, 5 cooperative block walk  [NBODY_BH_VARIANT]
+    int bh_walk_lds_block = 1024;  // variant 3: threads per workgroup                                                              [NBODY_BH_LDS_BLOCK]
+    int bh_hot_cap = 2048;      // variant 3: node records staged in LDS per workgroup                                              [NBODY_BH_HOT]
+    int bh_walk_debug = 0;      // 1: per-wave start/end stamps (tools/bh_wave_times.py)
+    int sym_debug = 0;          // 4: in-kernel cycle stamps (tools/sym_cycles.py); 5-7: timing experiments that do not compute the forces
+};
+const Tuning& tuning();                 // of the handle this thread is serving; the defaults outside a call
+void bind_tuning(const Tuning* t);      // (nullptr: back to the defaults)
+
 // Device-resident body state of one shard.  Positions of ALL shards live in `pos_all`
 // (world_size segments of `seg_cap` float4 {x,y,z,m}); velocities and accelerations only for
 // the shard's own segment.  Body counts are device-resident so that bodies can leave the box

@@ -182,14 +182,13 @@ static void launch_fast_cfg(hipStream_t s, const Shard& sh, int n_upper, float g
 }  // namespace nbody
 // 0 = default; != 0 forces the LDS-tiled one-sided kernel with that many bodies per lane (1, 2, 4) even
 // where the symmetric kernel would be used: tuning/test hook (NBODY_BF_VARIANT environment variable)
-extern "C" int nbody_bf_fast_variant = 0;
 namespace nbody {
 
 void launch_bf_forces_fast(hipStream_t s, const Shard& sh, int n_upper, float g, float g_soft2) {
     if (n_upper <= 0) return;
     // one body per lane, 8 waves splitting each partner tile, measured fastest at every size once
     // SLP vectorisation was off (tools/tune_bf.py); 2 and 4 bodies per lane stay selectable
-    switch (nbody_bf_fast_variant) {
+    switch (tuning().bf_fast_variant) {
         case 4: launch_fast_cfg<4, 8, 2048>(s, sh, n_upper, g, g_soft2); break;
         case 2: launch_fast_cfg<2, 8, 2048>(s, sh, n_upper, g, g_soft2); break;
         default: launch_fast_cfg<1, 8, 2048>(s, sh, n_upper, g, g_soft2); break;

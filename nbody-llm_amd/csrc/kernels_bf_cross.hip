@@ -20,11 +20,7 @@
 
 #include <algorithm>
 
-extern "C" int nbody_sym_packed;
 // tuning knobs of the plan (tools/tune_sharded.py); every rank of a world must use the same values
-extern "C" int nbody_cross_slots = 3072;  // waves the chunk visits are dealt to
-extern "C" int nbody_cross_ipt = 0;       // resident bodies per lane: 0 = by the rule below, 4, 8
-extern "C" int nbody_cross_wpb = 4;       // waves per workgroup: 4, 8, 12 (4: three times as many workgroups as CUs, dealt evenly;
                                           // 12 = one workgroup per CU left CUs idle: G = 8, N = 65 536: 0.100 against 0.114 ms)
 
 namespace nbody {
@@ -167,7 +163,7 @@ CrossPlan make_cross_plan(int rank, int G, int seg_cap, int n_own_upper) {
     // CAPACITY, which every rank knows, so that all ranks cut the opposite-rank pair at the same chunk.
     const int chunks_cap = (seg_cap + 63) / 64;                 // chunks a shard can hold
     const long long visits8 = (long long)((seg_cap + 511) / 512) * chunks_cap * std::max(1, G / 2);
-    const int IPT = (nbody_cross_ipt == 4 || nbody_cross_ipt == 8) ? nbody_cross_ipt : (visits8 < 3072) ? 4 : 8;
+    const int IPT = (tuning().cross_ipt == 4 || tuning().cross_ipt == 8) ? tuning().cross_ipt : (visits8 < 3072) ? 4 : 8;
     p.ipt = IPT;
     p.A = (n_own_upper + 64 * IPT - 1) / (64 * IPT);
     // opposite ranks: the lower rank takes the higher rank's chunks below `split`, the higher rank keeps
@@ -203,7 +199,7 @@ CrossPlan make_cross_plan(int rank, int G, int seg_cap, int n_own_upper) {
         for (int i = 0; i < q.n; ++i) if (a >= q.a0[i] && a < q.a1[i]) L[a] += q.c1[i] - q.c0[i];
         total += L[a];
     }
-    const int slots = std::max(256, nbody_cross_slots);
+    const int slots = std::max(256, tuning().cross_slots);
     const double target = std::max(1.0, double(total) / double(slots));
     int kmax = 1;
     std::vector<int> Ka(p.A, 0);
@@ -227,11 +223,11 @@ void launch_bf_cross(hipStream_t s, const Shard& sh, const CrossPlan& p, const i
     if (p.slices.empty() || p.parts.n == 0) return;
     const int n_slices = int(p.slices.size());
 #define CROSS_LAUNCH(IPT, WPB, PKV) hipLaunchKernelGGL((k_bf_cross<IPT, WPB, PKV>), dim3((n_slices + WPB - 1) / WPB), dim3(WPB * 64), 0, s, sh.pos_all, sh.seg_count, sh.seg_cap, sh.my_seg, p.parts, d_slices, n_slices, p.A, res_planes, xplanes, plane_stride, g_soft2)
-#define CROSS_LAUNCH_W(IPT, PKV) do { if (nbody_cross_wpb == 4) CROSS_LAUNCH(IPT, 4, PKV); else if (nbody_cross_wpb == 8) CROSS_LAUNCH(IPT, 8, PKV); else CROSS_LAUNCH(IPT, 12, PKV); } while (0)
+#define CROSS_LAUNCH_W(IPT, PKV) do { if (tuning().cross_wpb == 4) CROSS_LAUNCH(IPT, 4, PKV); else if (tuning().cross_wpb == 8) CROSS_LAUNCH(IPT, 8, PKV); else CROSS_LAUNCH(IPT, 12, PKV); } while (0)
     // packed pairs only with 8 bodies per lane: with 4 a stage is two instructions long and the dependent
     // stages stall on each other (G = 8 at N = 65 536: 0.140 ms packed, 0.119 ms scalar)
     if (p.ipt == 4) CROSS_LAUNCH_W(4, false);
-    else if (nbody_sym_packed) CROSS_LAUNCH_W(8, true);
+    else if (tuning().sym_packed) CROSS_LAUNCH_W(8, true);
     else CROSS_LAUNCH_W(8, false);
 #undef CROSS_LAUNCH_W
 #undef CROSS_LAUNCH

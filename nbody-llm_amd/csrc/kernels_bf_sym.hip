@@ -34,7 +34,9 @@ namespace nbody {
 
 namespace {
 
+#ifdef NBODY_TUNING
 __device__ unsigned long long nbody_sym_stamps[3 * 8192];  // diagnostic builds only (DBG & 4)
+#endif
 
 }  // namespace
 
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
         return (j < n) ? pos[j] : make_float4(PAD_POS, PAD_POS, PAD_POS, 0.f);
     };
 
-    unsigned long long t_beg = 0, r_beg = 0;
+    [[maybe_unused]] unsigned long long t_beg = 0, r_beg = 0;
     if (DBG & 4) { t_beg = __builtin_amdgcn_s_memtime(); r_beg = __builtin_amdgcn_s_memrealtime(); }
     float4 nxt = (k0 < k1) ? load_chunk(k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     // packed form (PK): the resident bodies two per register pair, see bf_pair.h
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
     }
     if (PK) { unpack_pairs<IPT>(axi2, axi); unpack_pairs<IPT>(ayi2, ayi); unpack_pairs<IPT>(azi2, azi); }
 
+#ifdef NBODY_TUNING
     if (DBG & 4) {  // diagnostic build: shader cycles and 100 MHz ticks of this wave's chunk loop, into a
                     // buffer of their own that nothing else reads
         const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(WPB * 64) void k_bf_sym(const float4* __restrict__ 
             nbody_sym_stamps[gw * 3 + 2] = (unsigned long long)(k1 - k0) | ((unsigned long long)hw << 16) | ((unsigned long long)(xcc & 0xF) << 48);
         }
     }
+#endif
     if (res_combine) {
         // K is a multiple of WPB: the workgroup's waves are WPB consecutive slices of ONE set; their
         // resident-side sums are added in slice order through LDS and leave as one plane row set
@@ -442,13 +446,10 @@ __global__ __launch_bounds__(64 * Q) void k_bf_sym_reduce_split(const float4* __
 }
 
 }  // namespace nbody
+#ifdef NBODY_TUNING
 namespace nbody { int read_sym_stamps(unsigned long long* out, int n_waves); }
 extern "C" int nbody_sym_read_stamps(unsigned long long* out, int n_waves) { return nbody::read_sym_stamps(out, n_waves); }
-extern "C" int nbody_sym_wpb = 12;     // waves per workgroup: 16, 12 or 8   (tuning hooks, tools/tune_sym.py)
-extern "C" int nbody_sym_rounds = 1;   // rounds of workgroups per CU
-extern "C" int nbody_sym_debug = 0;    // 4: diagnostic build with in-kernel cycle stamps
-extern "C" int nbody_sym_reduce_split = 1;   // 1: several waves per 64 bodies in the plane reduction; 0: one thread per body
-extern "C" int nbody_sym_packed = 1;   // 1: packed-fp32 pair evaluation (pair_evals_pk), 0: scalar; env NBODY_SYM_PACKED
+#endif
 namespace nbody {
 
 // ----------------------------------------------------------------------------------- host side
@@ -462,19 +463,19 @@ SymPlan make_sym_plan(int n_upper) {
     // waves per set: every workgroup is CU-sized (wpb waves; the register budget admits 4 waves per
     // SIMD), so the grid is dealt evenly; `rounds` > 1 makes shorter waves in several rounds, which
     // trims the tail at the price of more resident-side planes
-    p.wpb = nbody_sym_wpb == 8 ? 8 : nbody_sym_wpb == 12 ? 12 : 16;
-    if (n_upper <= 8192 && nbody_sym_wpb == 12) p.wpb = 8;   // a small shard (8 GPUs at N = 65 536): one-chunk waves, smaller workgroups deal better (-9 us)
+    p.wpb = tuning().sym_wpb == 8 ? 8 : tuning().sym_wpb == 12 ? 12 : 16;
+    if (n_upper <= 8192 && tuning().sym_wpb == 12) p.wpb = 8;   // a small shard (8 GPUs at N = 65 536): one-chunk waves, smaller workgroups deal better (-9 us)
     const int resident_wgs_per_cu = (p.wpb == 8) ? 2 : 1;
     const int slots = 256 * resident_wgs_per_cu * p.wpb;  // waves the chip holds at once
     // A * K waves run in ceil(A*K/slots) rounds; pick the K (few, long slices preferred) whose last
     // round is fullest -- e.g. A = 2048 sets: K = 1 would fill 2/3 of one round, K = 3 fills two
     int K = 1;
     double best = 0.0;
-    const int k_hi = std::min(126, std::min(L, std::max(1, slots * std::max(1, nbody_sym_rounds) * 4 / p.A)));
+    const int k_hi = std::min(126, std::min(L, std::max(1, slots * std::max(1, tuning().sym_rounds) * 4 / p.A)));
     for (int k = 1; k <= k_hi; ++k) {
         const long long waves = (long long)p.A * k;
         const long long rounds = (waves + slots - 1) / slots;
-        if (rounds > 4 * std::max(1, nbody_sym_rounds) && k > 1) break;
+        if (rounds > 4 * std::max(1, tuning().sym_rounds) && k > 1) break;
         const double fill = double(waves) / double(rounds * slots);
         const double even = (L % k == 0) ? 1.0 : double(L / k) / double(L / k + 1);  // shortest/longest slice
         const double per_wave = double(L) / k / (double(L) / k + 0.3);  // set-up cost of a wave ~ 0.3 chunk
@@ -493,9 +494,11 @@ SymPlan make_sym_plan(int n_upper) {
     return p;
 }
 
+#ifdef NBODY_TUNING
 int read_sym_stamps(unsigned long long* out, int n_waves) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbody_sym_stamps), sizeof(unsigned long long) * 3 * n_waves) == hipSuccess ? 0 : -1;
 }
+#endif
 
 uint64_t sym_main_pairs(const SymPlan& p, size_t n) {
     const size_t set = size_t(64) * p.ipt;
@@ -514,20 +517,29 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
     const int rest_blocks = int(p.n_pad / 64);  // one workgroup per 64 bodies
     const dim3 grid(main_blocks + rest_blocks), block(p.wpb * 64);
 #define SYM_LAUNCH(WPB, DBG) hipLaunchKernelGGL((k_bf_sym<8, WPB, DBG, PKV>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.plane_stride, g_soft2, p.res_combine)
-    if (nbody_sym_packed) {
+#ifdef NBODY_TUNING   // in-kernel stamps (tools/sym_cycles.py: 4) and timing experiments that do not compute the forces (5-7)
+    const int dbg = tuning().sym_debug;
+#else
+    constexpr int dbg = 0;
+#endif
+    if (tuning().sym_packed) {
         constexpr bool PKV = true;
-        if (nbody_sym_debug == 4) {  // in-kernel stamps (tools/sym_cycles.py)
+        if (dbg == 4) {
+#ifdef NBODY_TUNING
             if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
+#endif
         } else {
             if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
         }
     } else {
         constexpr bool PKV = false;
-        if (nbody_sym_debug == 4) {
-            if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
-        } else if (nbody_sym_debug == 5) { SYM_LAUNCH(16, 5);   // timing experiments: wrong results
-        } else if (nbody_sym_debug == 6) { SYM_LAUNCH(16, 6);
-        } else if (nbody_sym_debug == 7) { SYM_LAUNCH(16, 7);
+        if (dbg >= 4 && dbg <= 7) {
+#ifdef NBODY_TUNING
+            if (dbg == 4) { if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4); }
+            else if (dbg == 5) SYM_LAUNCH(16, 5);
+            else if (dbg == 6) SYM_LAUNCH(16, 6);
+            else SYM_LAUNCH(16, 7);
+#endif
         } else {
             if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
         }
@@ -539,7 +551,7 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
 void launch_bf_os(hipStream_t s, const Shard& sh, int A, int K, float4* planes, size_t plane_stride, float g_soft2) {
     if (A <= 0 || K <= 0) return;
     const int wpb = 12;
-    if (nbody_sym_packed)
+    if (tuning().sym_packed)
         hipLaunchKernelGGL((k_bf_os<8, 12, true>), dim3((A * K + wpb - 1) / wpb), dim3(wpb * 64), 0, s, sh.pos_all,
                            sh.seg_count, sh.n_seg, sh.seg_cap, sh.my_seg, A, K, planes, plane_stride, g_soft2);
     else
@@ -560,7 +572,7 @@ void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4
     }
     const float dt = kick_dt ? *kick_dt : 0.f;
 #define REDUCE_ARGS planes, p.n_planes, p.plane_stride, sh.own_count(), g, sh.acc, sh.own_pos(), sh.vel, dt, sh.seg_count, sh.n_seg, sh.inter
-    if (nbody_sym_reduce_split && p.n_planes >= 16) {   // several waves per 64 bodies: 16 for small shards, 4 otherwise
+    if (tuning().sym_reduce_split && p.n_planes >= 16) {   // several waves per 64 bodies: 16 for small shards, 4 otherwise
         const dim3 grid((n_upper + 63) / 64);
         if (n_upper <= 16384) {
             if (kick_dt) hipLaunchKernelGGL((k_bf_sym_reduce_split<true, 16>), grid, dim3(1024), 0, s, REDUCE_ARGS);

@@ -67,7 +67,9 @@ __device__ __forceinline__ int walk_entry(const NodeDev* __restrict__ nodes, con
     return s0;  // every ancestor was opened: the walk arrives at first[seg] itself
 }
 
+#ifdef NBODY_TUNING
 __device__ unsigned long long nbody_bh_stamps[3 * 65536];  // diagnostic build only (DBG): per wave start, end (100 MHz ticks), iterations
+#endif
 
 // DIRECT = NBODY_LEAF_DIRECT: the walk of src/llm/barnes_hut.rs:915-997 on the same tree (see nbody_hip.h)
 template <bool FAST, bool DIRECT = false, bool DBG = false, int BLOCK = kWalkBlock>
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
     if (split.n_order_dev) n_order = min(n_order, *split.n_order_dev);
     const int s1 = split.first[seg + 1];
     unsigned int n_acc = 0, n_vis = 0;
-    unsigned long long r_beg = 0;
+    [[maybe_unused]] unsigned long long r_beg = 0;
     if (DBG) r_beg = __builtin_amdgcn_s_memrealtime();
     if (t < n_order) {
         const int b = order[t];
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
         *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) =
             make_float4(ax, ay, az, split.store_work ? float(n_vis) : 0.f);  // :260
     }
+#ifdef NBODY_TUNING
     if (DBG) {
         unsigned int it = n_vis;
         for (int off = 32; off > 0; off >>= 1) it = max(it, (unsigned int)__shfl_down(it, off));
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
             nbody_bh_stamps[3 * w + 2] = (unsigned long long)it | ((unsigned long long)hw << 20) | ((unsigned long long)(xcc & 0xF) << 52);
         }
     }
+#endif
     // one atomic pair per wave
     for (int off = 32; off > 0; off >>= 1) {
         n_acc += __shfl_down(n_acc, off);
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
     }
 }
 
+#ifdef NBODY_TUNING   // ---- experimental walks (variants 1 and 2): measured, slower, kept reproducible in the tuning build only
 // Wave-cooperative form of the same walk.  The 64 lanes of a wave hold 64 neighbouring bodies
 // (tree order) and step through the UNION of their node sequences together: the node index is
 // wave-uniform, so the 32-byte node record arrives by scalar load in SGPRs (no divergent gather),
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
 // changes.  Measured at N = 65 536, theta = 0.5 with the node range split 8 ways: 0.60 ms against 0.53
 // for the per-lane walk -- the union of 64 neighbours' node sequences is several times longer than one
 // body's, which costs more than the divergent gathers it saves (groups of 4/8/16/32 lanes were tried
-// too: 0.60/0.63/0.68/0.77 ms).  Kept as a selectable variant (nbody_bh_walk_variant = 1).
+// too: 0.60/0.63/0.68/0.77 ms).  Kept as a selectable variant (tuning().bh_walk_variant = 1).
 template <bool FAST>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_wave(const NodeDev* __restrict__ nodes, int n_nodes,
                                                              const int* __restrict__ order, int n_order,
@@ -334,6 +339,8 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_pair(const NodeDev* __re
     }
 }
 
+#endif  // NBODY_TUNING
+
 // Strict math, reference leaf rule: the reference's NESTED sums (barnes_hut.rs:196-202: every opened
 // cell folds its children's results left to right from zero and hands the sum up).  One running sum
 // per lane reproduces the visits but not that association; this kernel keeps, per lane, the open
@@ -420,6 +427,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_nested(const NodeDev* __
 }
 
 
+#ifdef NBODY_TUNING   // ---- experimental walks (variants 4, 5, 3) and the stamp read-out: tuning build only
 // ---- Variant 4: wave-cooperative walk over a window of node records in LDS.
 // The 64 lanes of a wave (64 tree-order neighbours) step through the UNION of their node sequences with a
 // wave-uniform node index; lane l takes part in node i iff i >= resume[l] (= its own walk would visit i), the wave
@@ -803,16 +811,11 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk_lds(const NodeDev* __restrict
 }
 
 }  // namespace nbody
-extern "C" int nbody_bh_walk_debug = 0;    // 1: per-wave start/end stamps (tools/bh_wave_times.py)
 extern "C" int nbody_bh_read_stamps(unsigned long long* out, int n_waves) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbody::nbody_bh_stamps), sizeof(unsigned long long) * 3 * n_waves) == hipSuccess ? 0 : -1;
 }
-extern "C" int nbody_bh_reduce_split = 1;  // 1: four waves per 64 bodies in the plane reduction when there are >= 8 segments
-extern "C" int nbody_bh_walk_split = 0;    // node-range segments per body group: 0 = automatic
-extern "C" int nbody_bh_walk_order = 1;    // 1: a group's segments are dispatched nearest-first (heaviest first), 0: in index order
-extern "C" int nbody_bh_walk_variant = 0;  // 0 = one independent walk per lane (default), 1 = wave-cooperative (scalar loads), 2 = two lanes per body, 3 = hot records in LDS, 4 = wave-cooperative over a window of records, 5 = cooperative block walk (level-order copy)
-extern "C" int nbody_bh_walk_lds_block = 1024;  // variant 3: threads per workgroup (they share one LDS table)
 namespace nbody {
+#endif  // NBODY_TUNING
 
 // KICK: integrate_after_force (shared.rs:141-148) rides along, as in k_bf_sym_reduce
 template <bool KICK>
@@ -884,6 +887,58 @@ __global__ __launch_bounds__(64 * Q) void k_bh_reduce_split(const float4* __rest
     }
 }
 
+#ifdef NBODY_TUNING
+// The experimental walks of the tuning build (Tuning::bh_walk_variant 1..5) and the stamped instantiations
+// (Tuning::bh_walk_debug); returns false when the default walk is to run.
+static bool launch_walk_variant(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2, int fast_math,
+                                unsigned long long* counters, int leaf_direct, const WalkSplit& sp, dim3 grid) {
+    if (fast_math && tuning().bh_walk_variant == 3 && t.hot_cap > 0 && t.walk) {
+        const int M = t.hot_cap;
+        const dim3 pg((t.n_nodes + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_walk_slots, pg, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.hot_threshold, M, t.unified, t.hot_info);
+        hipLaunchKernelGGL(k_walk_links, pg, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, M, t.unified,
+                           reinterpret_cast<NodeDev*>(t.walk), reinterpret_cast<NodeDev*>(t.hot), t.hot_info);
+        const int groups = (t.n_order + 63) / 64;
+        const long long waves = (long long)groups * t.n_split;
+        const size_t lds_bytes = size_t(M) * sizeof(NodeDev);
+#define WALK_LDS(DIRECT, BLK) do {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bh_walk_lds<DIRECT, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipLaunchKernelGGL((k_bh_walk_lds<DIRECT, BLK>), dim3(unsigned((waves + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), lds_bytes, s,   \
+                               reinterpret_cast<const NodeDev*>(t.nodes), reinterpret_cast<const NodeDev*>(t.walk),         \
+                               reinterpret_cast<const NodeDev*>(t.hot), M, t.unified, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp); } while (0)
+        if (tuning().bh_walk_lds_block == 512) { if (leaf_direct) WALK_LDS(true, 512); else WALK_LDS(false, 512); }
+        else if (tuning().bh_walk_lds_block == 256) { if (leaf_direct) WALK_LDS(true, 256); else WALK_LDS(false, 256); }
+        else { if (leaf_direct) WALK_LDS(true, 1024); else WALK_LDS(false, 1024); }
+#undef WALK_LDS
+        return true;
+    }
+    if (fast_math && tuning().bh_walk_variant == 5 && t.bfs && t.n_nodes > 0) {
+        (void)build_bfs_layout(s, t.nodes, t.n_nodes, t.bfs_ws, t.bfs_cap, t.bfs);
+#define WALK_BLOCK(...) hipLaunchKernelGGL((k_bh_walk_block<__VA_ARGS__>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.bfs), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
+        if (tuning().bh_walk_debug && !leaf_direct) WALK_BLOCK(false, true);
+        else if (leaf_direct) WALK_BLOCK(true);
+        else WALK_BLOCK(false);
+#undef WALK_BLOCK
+        return true;
+    }
+    if (fast_math && tuning().bh_walk_variant == 4) {
+        if (tuning().bh_walk_debug && !leaf_direct) hipLaunchKernelGGL((k_bh_walk_coop<false, true>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
+        else if (leaf_direct) hipLaunchKernelGGL((k_bh_walk_coop<true>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
+        else hipLaunchKernelGGL((k_bh_walk_coop<false>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
+        return true;
+    }
+    // the alternative walks 1 and 2 are fast-math experiments with the reference leaf rule only
+    const int variant = (leaf_direct || !fast_math) ? 0 : (tuning().bh_walk_variant >= 3 ? 0 : tuning().bh_walk_variant);
+    if (variant == 2) grid.x = (2 * t.n_order + kWalkBlock - 1) / kWalkBlock;
+#define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
+    if (variant == 1) { WALK(k_bh_walk_wave, true); return true; }
+    if (variant == 2) { WALK(k_bh_walk_pair, true); return true; }
+    if (tuning().bh_walk_debug && fast_math && !leaf_direct) { WALK(k_bh_walk, true, false, true); return true; }   // per-wave stamps (tools/bh_wave_times.py)
+#undef WALK
+    return false;
+}
+#endif  // NBODY_TUNING
+
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters, int leaf_direct, const float* kick_dt, int* kicked) {
     if (kicked) *kicked = 0;
@@ -897,64 +952,30 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
     WalkSplit sp;
     sp.n_seg = t.n_split; sp.first = t.split_first; sp.anc = t.split_anc; sp.n_anc = t.split_n_anc;
     sp.planes = t.split_planes; sp.plane_stride = t.split_stride;
-    sp.diag_first = nbody_bh_walk_order;
+    sp.diag_first = tuning().bh_walk_order;
     sp.poison = t.poison; sp.n_order_dev = t.n_order_dev;
     sp.store_work = t.store_work;
     dim3 grid((t.n_order + kWalkBlock - 1) / kWalkBlock, t.n_split);
-    if (fast_math && nbody_bh_walk_variant == 3 && t.hot_cap > 0 && t.walk) {
-        const int M = t.hot_cap;
-        const dim3 pg((t.n_nodes + 1 + 255) / 256);
-        hipLaunchKernelGGL(k_walk_slots, pg, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.hot_threshold, M, t.unified, t.hot_info);
-        hipLaunchKernelGGL(k_walk_links, pg, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, M, t.unified,
-                           reinterpret_cast<NodeDev*>(t.walk), reinterpret_cast<NodeDev*>(t.hot), t.hot_info);
-        const int groups = (t.n_order + 63) / 64;
-        const long long waves = (long long)groups * t.n_split;
-        const size_t lds_bytes = size_t(M) * sizeof(NodeDev);
-#define WALK_LDS(DIRECT, BLK) do {                                                                                          \
-            static bool attr_set = false;                                                                                   \
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bh_walk_lds<DIRECT, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-            hipLaunchKernelGGL((k_bh_walk_lds<DIRECT, BLK>), dim3(unsigned((waves + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), lds_bytes, s,   \
-                               reinterpret_cast<const NodeDev*>(t.nodes), reinterpret_cast<const NodeDev*>(t.walk),         \
-                               reinterpret_cast<const NodeDev*>(t.hot), M, t.unified, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp); } while (0)
-        if (nbody_bh_walk_lds_block == 512) { if (leaf_direct) WALK_LDS(true, 512); else WALK_LDS(false, 512); }
-        else if (nbody_bh_walk_lds_block == 256) { if (leaf_direct) WALK_LDS(true, 256); else WALK_LDS(false, 256); }
-        else { if (leaf_direct) WALK_LDS(true, 1024); else WALK_LDS(false, 1024); }
-#undef WALK_LDS
-    } else {
-    if (fast_math && nbody_bh_walk_variant == 5 && t.bfs && t.n_nodes > 0) {
-        (void)build_bfs_layout(s, t.nodes, t.n_nodes, t.bfs_ws, t.bfs_cap, t.bfs);
-#define WALK_BLOCK(...) hipLaunchKernelGGL((k_bh_walk_block<__VA_ARGS__>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.bfs), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
-        if (nbody_bh_walk_debug && !leaf_direct) WALK_BLOCK(false, true);
-        else if (leaf_direct) WALK_BLOCK(true);
-        else WALK_BLOCK(false);
-#undef WALK_BLOCK
-    } else if (fast_math && nbody_bh_walk_variant == 4) {
-        if (nbody_bh_walk_debug && !leaf_direct) hipLaunchKernelGGL((k_bh_walk_coop<false, true>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
-        else if (leaf_direct) hipLaunchKernelGGL((k_bh_walk_coop<true>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
-        else hipLaunchKernelGGL((k_bh_walk_coop<false>), grid, dim3(64), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp);
-    } else {
-    // the alternative walks are fast-math experiments with the reference leaf rule only
-    const int variant = (leaf_direct || !fast_math) ? 0 : (nbody_bh_walk_variant >= 3 ? 0 : nbody_bh_walk_variant);
-    if (variant == 2) grid.x = (2 * t.n_order + kWalkBlock - 1) / kWalkBlock;
+    bool launched = false;
+#ifdef NBODY_TUNING   // the experimental walks (fast math only; 1 and 2: reference leaf rule only) and the stamped instantiations
+    launched = launch_walk_variant(s, sh, t, g, g_soft2, theta2, fast_math, counters, leaf_direct, sp, grid);
+#endif
+    if (!launched) {
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
-    if (variant == 1) WALK(k_bh_walk_wave, true);
-    else if (variant == 2) WALK(k_bh_walk_pair, true);
-    else if (t.n_split <= 2 && !nbody_bh_walk_debug) {
-        // enough bodies to fill the chip with one or two segments (N >= ~2.5e5): 256-thread workgroups are up to
-        // 10 % faster there (6.2 against 6.8 ms at N = 2^20); with more segments one-wave workgroups win (kWalkBlock)
-        grid = dim3((t.n_order + 255) / 256, t.n_split);
+        if (t.n_split <= 2) {
+            // enough bodies to fill the chip with one or two segments (N >= ~2.5e5): 256-thread workgroups are up to
+            // 10 % faster there (6.2 against 6.8 ms at N = 2^20); with more segments one-wave workgroups win (kWalkBlock)
+            grid = dim3((t.n_order + 255) / 256, t.n_split);
 #define WALK256(...) hipLaunchKernelGGL((k_bh_walk<__VA_ARGS__, false, 256>), grid, dim3(256), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
-        if (leaf_direct) { if (fast_math) WALK256(true, true); else WALK256(false, true); }
-        else { if (fast_math) WALK256(true, false); else WALK256(false, false); }
+            if (leaf_direct) { if (fast_math) WALK256(true, true); else WALK256(false, true); }
+            else { if (fast_math) WALK256(true, false); else WALK256(false, false); }
 #undef WALK256
-    }
-    else if (leaf_direct) { if (fast_math) WALK(k_bh_walk, true, true); else WALK(k_bh_walk, false, true); }
-    else if (nbody_bh_walk_debug && fast_math) WALK(k_bh_walk, true, false, true);
-    else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
+        }
+        else if (leaf_direct) { if (fast_math) WALK(k_bh_walk, true, true); else WALK(k_bh_walk, false, true); }
+        else { if (fast_math) WALK(k_bh_walk, true); else WALK(k_bh_walk, false); }
 #undef WALK
     }
-    }
-    if (t.n_split >= 8 && fast_math && nbody_bh_reduce_split) {   // (strict math never splits; the plain form keeps the single walk's order)
+    if (t.n_split >= 8 && fast_math && tuning().bh_reduce_split) {   // (strict math never splits; the plain form keeps the single walk's order)
         const dim3 rg((t.n_order + 63) / 64);
         if (kick_dt) {
             hipLaunchKernelGGL((k_bh_reduce_split<true, 4>), rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order, t.n_order,

@@ -33,7 +33,6 @@
 
 // test hook: the largest group of equal 63-bit keys the device build orders itself (1: any collision is "too deep", which
 // exercises the callers' fallback paths the way every collision did before the second keys existed)
-extern "C" int nbody_tree_max_tie = 64;
 
 namespace nbody {
 
@@ -109,7 +108,7 @@ __device__ __forceinline__ int common_levels2(const unsigned long long* __restri
 // group of equal TOP bits (bodies that share 16 levels: a handful here and there) sorts the group by the full key
 // (insertion sort; the radix sort is stable, so equal keys keep ascending ids), and inside it every run of equal FULL
 // keys gets its second keys (levels 21..41) and is put in their order.  Groups are pairs in practice; a group of more
-// than kMaxLowGroup bodies, or a run of more than nbody_tree_max_tie (64) equal keys, is reported as too deep rather than
+// than kMaxLowGroup bodies, or a run of more than tuning().tree_max_tie (64) equal keys, is reported as too deep rather than
 // sorted by a single thread.
 constexpr int kSortLowBits = 15;    // key bits the radix sort leaves to k_tree_ties (levels 16..20)
 constexpr int kMaxLowGroup = 256;
@@ -549,7 +548,7 @@ int sort_keys_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, c
     // tail comes last in the input; k_tree_ties finishes the low bits)
     if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), kSortLowBits, 63, s) != hipSuccess) return -1;
     hipLaunchKernelGGL((k_tree_ties<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width,
-                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, nbody_tree_max_tie));
+                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie));
     return 0;
 }
 template <class P4>
@@ -633,6 +632,7 @@ void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_
                        n_split, first, n_anc, anc, max_anc, info, poison);
 }
 
+#ifdef NBODY_TUNING   // (the cooperative block walk is one of the experimental walks: tuning build only)
 // ---- level-order copy of the tree for the cooperative block walk (kernels_bh.hip k_bh_walk_block): the nodes sorted
 // by depth, ties in pre-order, so that the children of a node are consecutive records (all descendants of a node at
 // one depth lie between its pre-order bounds).  Record: {com, mass | w^2, pre-order index, pre-order skip link,
@@ -706,6 +706,8 @@ int build_bfs_layout(hipStream_t s, const float4* nodes, int n_nodes, void* work
     hipLaunchKernelGGL(k_bfs_records, grid, block, 0, s, nodes, n_nodes, perm, pos, depth, out);
     return 0;
 }
+
+#endif  // NBODY_TUNING
 
 // bytes at the start of the build workspace that rocPRIM uses as scratch (free between builds)
 size_t tree_build_tmp_bytes(size_t n_cap) { return scratch_bytes(n_cap); }

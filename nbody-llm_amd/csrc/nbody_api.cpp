@@ -20,15 +20,6 @@
 #include <thread>
 #include <vector>
 
-extern "C" int nbody_bf_fast_variant;
-extern "C" int nbody_sym_wpb;
-extern "C" int nbody_sym_rounds;
-extern "C" int nbody_sym_packed;
-extern "C" int nbody_bh_walk_split;
-extern "C" int nbody_bh_walk_variant;
-extern "C" int nbody_bh_walk_lds_block;
-extern "C" int nbody_bh_hot_cap = 2048;  // fast walk, variant 3: node records staged in LDS per workgroup (32 B each)
-extern "C" int nbody_cross_sym = 1;  // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided
 
 static thread_local std::string g_create_err;
 
@@ -63,6 +54,7 @@ void* pinned_alloc(size_t n) {
 void pinned_free(void* p) { (void)hipHostFree(p); }
 
 int use_device(NbodyHandle* h) {
+    nbody::bind_tuning(&h->tune);   // the launchers below read this handle's knobs (kernels.h)
     HIP_TRY(h, hipSetDevice(h->device));
     return NBODY_OK;
 }
@@ -181,7 +173,7 @@ constexpr size_t kShardedSymMinBodies = 2048; // sharded: own-own symmetric + re
 // (re)build the symmetric kernel's plan when the number of resident sets changes
 int ensure_sym_plan(NbodyHandle* h) {
     const int A = int((std::max<size_t>(1, h->n_local) + 511) / 512);  // (an empty shard still plans one set)
-    const int knobs = nbody_sym_wpb * 100 + nbody_sym_rounds;
+    const int knobs = nbody::tuning().sym_wpb * 100 + nbody::tuning().sym_rounds;
     if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == knobs) return NBODY_OK;
     h->sym_waves = knobs;
     h->sym_plan = nbody::make_sym_plan(int(std::max<size_t>(1, h->n_local)));
@@ -190,7 +182,7 @@ int ensure_sym_plan(NbodyHandle* h) {
     if (h->sh.n_seg > 1) {
         const size_t cap_pad = (size_t(h->sh.seg_cap) + 63) / 64 * 64;
         p.plane_stride = std::max(p.n_pad, cap_pad);
-        if (nbody_cross_sym && h->sh.n_seg <= 2 * (nbody::CrossPartners::kMax - 1)) {
+        if (nbody::tuning().cross_sym && h->sh.n_seg <= 2 * (nbody::CrossPartners::kMax - 1)) {
             // every unordered pair between shards once: this GPU is resident for some partners and
             // receives the partial sums the others accumulated for its bodies
             h->cross = nbody::make_cross_plan(h->sh.my_seg, h->sh.n_seg, h->sh.seg_cap, int(std::max<size_t>(1, h->n_local)));
@@ -244,7 +236,7 @@ int ensure_sym_plan(NbodyHandle* h) {
 
 int bf_forces(NbodyHandle* h) {
     const float eps2 = h->g_soft * h->g_soft;  // brute_force.rs:69
-    const bool fast = h->cfg.math_mode == NBODY_MATH_FAST && nbody_bf_fast_variant == 0;
+    const bool fast = h->cfg.math_mode == NBODY_MATH_FAST && nbody::tuning().bf_fast_variant == 0;
     const bool sharded = h->sh.n_seg > 1;
     // Sharded: decided from the shard CAPACITY, which every rank shares.  The live counts differ from rank
     // to rank (ragged last block, bodies leaving the box), and a rank that chose another scheme than its
@@ -339,7 +331,6 @@ int bh_walk_device_tree_async(NbodyHandle* h);
 int resolve_async(NbodyHandle* h);
 int step_end(NbodyHandle* h, float dt);
 int step_impl(NbodyHandle* h, float dt);
-extern "C" int nbody_bh_walk_debug;
 
 // strict math with the reference leaf rule walks with the reference's nested sums (bit-exact): per own body a stack
 // of the open cells on its path, 16 bytes each -- as many levels as the tree is deep (the device build stops at 42;
@@ -364,8 +355,12 @@ int ensure_nested_stack(NbodyHandle* h, nbody::TreeDev* td) {
 // fast math, variant 3: buffers of the LDS-staged walk and the threshold that picks the staged nodes.
 // Called after this step's first host synchronisation, so h_hot_info holds the previous pass's flagged count.
 int setup_lds_walk(NbodyHandle* h, nbody::TreeDev* td, size_t n_tree) {
+#ifndef NBODY_TUNING
+    (void)h; (void)td; (void)n_tree;   // (the experimental walks live in the tuning build)
+    return NBODY_OK;
+#else
     // (its stack holds the 42 levels of the device build; a deeper host-built tree is walked by k_bh_walk)
-    if (h->cfg.math_mode == NBODY_MATH_FAST && nbody_bh_walk_variant == 5 && (h->tree_on_device || h->tree.max_depth <= 42)) {
+    if (h->cfg.math_mode == NBODY_MATH_FAST && nbody::tuning().bh_walk_variant == 5 && (h->tree_on_device || h->tree.max_depth <= 42)) {
         if (h->bfs_cap < h->d_node_cap) {
             if (h->d_bfs) (void)hipFree(h->d_bfs);
             if (h->d_bfs_ws) (void)hipFree(h->d_bfs_ws);
@@ -377,8 +372,8 @@ int setup_lds_walk(NbodyHandle* h, nbody::TreeDev* td, size_t n_tree) {
         td->bfs = h->d_bfs; td->bfs_ws = h->d_bfs_ws; td->bfs_cap = h->bfs_cap;
         return NBODY_OK;
     }
-    if (h->cfg.math_mode != NBODY_MATH_FAST || nbody_bh_walk_variant != 3 || nbody_bh_hot_cap <= 0) return NBODY_OK;
-    const int M = std::min(nbody_bh_hot_cap, 5000);  // 160 KB of LDS per CU, 32 B per record
+    if (h->cfg.math_mode != NBODY_MATH_FAST || nbody::tuning().bh_walk_variant != 3 || nbody::tuning().bh_hot_cap <= 0) return NBODY_OK;
+    const int M = std::min(nbody::tuning().bh_hot_cap, 5000);  // 160 KB of LDS per CU, 32 B per record
     if (h->walk_cap < h->d_node_cap) {
         if (h->d_walk) (void)hipFree(h->d_walk);
         if (h->d_unified) (void)hipFree(h->d_unified);
@@ -413,6 +408,7 @@ int setup_lds_walk(NbodyHandle* h, nbody::TreeDev* td, size_t n_tree) {
     td->walk = h->d_walk; td->unified = h->d_unified; td->hot = h->d_hot; td->hot_info = h->d_hot_info;
     td->hot_cap = M; td->hot_threshold = h->hot_threshold;
     return NBODY_OK;
+#endif
 }
 
 int bh_forces(NbodyHandle* h) {
@@ -424,8 +420,8 @@ int bh_forces(NbodyHandle* h) {
     h->last_step_async = false;
     if (h->cfg.tree_build == NBODY_TREE_DEVICE && !h->host_tree_once) {
         // no read-back at all: single shard, the plain or the strict walk (the experimental walks want the node count)
-        const bool plain_walk = h->cfg.math_mode == NBODY_MATH_STRICT || nbody_bh_walk_variant == 0;
-        if (h->async_bh && plain_walk && !nbody_bh_walk_debug) return bh_walk_device_tree_async(h);
+        const bool plain_walk = h->cfg.math_mode == NBODY_MATH_STRICT || nbody::tuning().bh_walk_variant == 0;
+        if (h->async_bh && plain_walk && !nbody::tuning().bh_walk_debug) return bh_walk_device_tree_async(h);
         int rc = resolve_async(h);
         if (rc) return rc;
         bool fell_back = false;
@@ -484,14 +480,14 @@ int bh_forces(NbodyHandle* h) {
     // the chip (>= 8 waves per SIMD wanted: the walk is bound by the latency of dependent loads)
     {
         constexpr int kMaxSplit = 64, kMaxAnc = 192;
-        // ~3 waves per wave slot of the chip (256 CUs x 32), handed out heaviest first (nbody_bh_walk_order): the launch
+        // ~3 waves per wave slot of the chip (256 CUs x 32), handed out heaviest first (nbody::tuning().bh_walk_order): the launch
         // lasts as long as its slowest wave, and smaller pieces started in the right order shorten that tail
         // (N = 65 536: 24 segments 0.310 ms, 8 segments 0.336 ms; tools/tune_bh_order.py)
-        int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+        int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
         K = std::max(1, std::min(kMaxSplit, K));
         // strict math is the parity path: one segment, so every lane adds in the reference's order (bit-exact)
-        if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;
-        while (nbody_bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > h->tree.n_nodes) K /= 2;   // (a pinned split is taken as given)
+        if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody::tuning().bh_walk_split <= 0) K = 1;
+        while (nbody::tuning().bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > h->tree.n_nodes) K /= 2;   // (a pinned split is taken as given)
         if (K > 1) {
             if (!h->d_split) {
                 HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
@@ -597,7 +593,7 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (nbody::build_octree_device(h->stream, tree_pos, tree_count, int(tot_upper), h->center, h->width,
                                        h->d_tree_ws, n_cap, h->d_nodes, int(h->d_node_cap), h->d_order, h->d_tree_info,
-                                       &work, nbody_bh_walk_variant == 3) != 0)
+                                       &work, nbody::tuning().bh_walk_variant == 3) != 0)
             return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(h->h_tree_info, h->d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -632,10 +628,10 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
         HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
         HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
     }
-    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
+    int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
     K = std::max(1, std::min(kMaxSplit, K));
-    if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
-    while (nbody_bh_walk_split <= 0 && K > 1 && K * 16 > n_nodes) K /= 2;
+    if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody::tuning().bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
+    while (nbody::tuning().bh_walk_split <= 0 && K > 1 && K * 16 > n_nodes) K /= 2;
     if (n_order == 0) K = 1;
     nbody::TreeDev td;
     td.nodes = h->d_nodes; td.n_nodes = n_nodes;
@@ -712,10 +708,10 @@ int bh_walk_device_tree_async(NbodyHandle* h) {
         HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
     }
     const size_t groups = std::max<size_t>(1, (n_upper + 63) / 64);
-    int K = nbody_bh_walk_split > 0 ? nbody_bh_walk_split : int((16384 + groups - 1) / groups);
+    int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + groups - 1) / groups);
     K = std::max(1, std::min(kMaxSplit, K));
-    if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody_bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
-    while (nbody_bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > n_upper) K /= 2;   // (a tree has at least as many nodes as bodies)
+    if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody::tuning().bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
+    while (nbody::tuning().bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > n_upper) K /= 2;   // (a tree has at least as many nodes as bodies)
     if (n_upper == 0) K = 1;
     nbody::TreeDev td;
     td.nodes = h->d_nodes; td.n_nodes = int(h->d_node_cap);   // (the plain walks end at the split points, not at n_nodes)
@@ -1068,14 +1064,18 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
         int rc_let = nbody::let::create(h);
         if (rc_let) return bail(rc_let);
     }
-    if (const char* v = std::getenv("NBODY_BF_VARIANT")) nbody_bf_fast_variant = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_CROSS_SYM")) nbody_cross_sym = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_SYM_PACKED")) nbody_sym_packed = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_BH_VARIANT")) nbody_bh_walk_variant = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_BH_SPLIT")) nbody_bh_walk_split = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_BH_HOT")) nbody_bh_hot_cap = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_BH_LDS_BLOCK")) nbody_bh_walk_lds_block = std::atoi(v);
-    if (const char* v = std::getenv("NBODY_SYM_WPB")) nbody_sym_wpb = std::atoi(v);
+    {   // the documented environment switches set this handle's knobs (nbody_set_tuning changes them later)
+        nbody::Tuning& t = h->tune;
+        const struct { const char* env; int* knob; } table[] = {
+            {"NBODY_BF_VARIANT", &t.bf_fast_variant}, {"NBODY_CROSS_SYM", &t.cross_sym}, {"NBODY_SYM_PACKED", &t.sym_packed},
+            {"NBODY_BH_SPLIT", &t.bh_walk_split}, {"NBODY_SYM_WPB", &t.sym_wpb},
+#ifdef NBODY_TUNING
+            {"NBODY_BH_VARIANT", &t.bh_walk_variant}, {"NBODY_BH_HOT", &t.bh_hot_cap}, {"NBODY_BH_LDS_BLOCK", &t.bh_walk_lds_block},
+#endif
+        };
+        for (const auto& e : table)
+            if (const char* v = std::getenv(e.env)) *e.knob = std::atoi(v);
+    }
     *out = h;
     return NBODY_OK;
 }
@@ -1132,6 +1132,7 @@ int nbody_clone(const NbodyHandle* src, NbodyHandle** out) {
         return NBODY_ERR_HIP;
     }
     h->g = src->g; h->g_soft = src->g_soft; h->dt = src->dt; h->theta2 = src->theta2;
+    h->tune = src->tune;
     std::memcpy(h->center, src->center, sizeof(h->center));
     h->width = src->width; h->bnd = src->bnd; h->bounds_set = src->bounds_set;
     h->elapsed = src->elapsed;
@@ -1598,8 +1599,8 @@ int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_partials_done, hipEventDisableTiming));
     }
     Agreement mine{NBODY_ABI_VERSION, h->cfg.method, h->cfg.math_mode, h->cfg.leaf_mode, h->cfg.tree_build, h->cfg.dtype, h->cfg.shard_mode,
-                   h->cfg.world_size, h->sh.seg_cap, nbody_cross_sym, nbody_sym_packed, nbody_bf_fast_variant, nbody_bh_walk_variant,
-                   nbody_bh_walk_split, h->cfg.capacity};
+                   h->cfg.world_size, h->sh.seg_cap, nbody::tuning().cross_sym, nbody::tuning().sym_packed, nbody::tuning().bf_fast_variant, nbody::tuning().bh_walk_variant,
+                   nbody::tuning().bh_walk_split, h->cfg.capacity};
     std::vector<Agreement> all(size_t(h->cfg.world_size));
     TP_TRY(h, h->tp->host_all_gather(&mine, all.data(), sizeof(Agreement)));
     for (int r = 0; r < h->cfg.world_size; ++r) {
@@ -1618,6 +1619,54 @@ int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
     }
     h->comm_ready = true;
     return NBODY_OK;
+}
+
+// ---- launch-shape and scheme knobs of one handle (kernels.h struct Tuning)
+namespace {
+struct Knob { const char* name; int nbody::Tuning::*field; bool tuning_build_only; };
+const Knob kKnobs[] = {
+    {"cross_sym", &nbody::Tuning::cross_sym, false}, {"sym_packed", &nbody::Tuning::sym_packed, false},
+    {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false},
+    {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
+    {"cross_slots", &nbody::Tuning::cross_slots, false}, {"cross_ipt", &nbody::Tuning::cross_ipt, false},
+    {"cross_wpb", &nbody::Tuning::cross_wpb, false}, {"bh_walk_split", &nbody::Tuning::bh_walk_split, false},
+    {"bh_walk_order", &nbody::Tuning::bh_walk_order, false}, {"bh_reduce_split", &nbody::Tuning::bh_reduce_split, false},
+    {"tree_max_tie", &nbody::Tuning::tree_max_tie, false},
+    {"bh_walk_variant", &nbody::Tuning::bh_walk_variant, true}, {"bh_walk_lds_block", &nbody::Tuning::bh_walk_lds_block, true},
+    {"bh_hot_cap", &nbody::Tuning::bh_hot_cap, true}, {"bh_walk_debug", &nbody::Tuning::bh_walk_debug, true},
+    {"sym_debug", &nbody::Tuning::sym_debug, true},
+};
+}  // namespace
+
+int nbody_set_tuning(NbodyHandle* h, const char* name, int value) {
+    if (!h || !name) return NBODY_ERR_INVALID;
+    for (const Knob& k : kKnobs)
+        if (std::strcmp(k.name, name) == 0) {
+#ifndef NBODY_TUNING
+            if (k.tuning_build_only && value != nbody::Tuning{}.*(k.field))
+                return fail(h, NBODY_ERR_INVALID, std::string("nbody_set_tuning: '") + name + "' selects code only the tuning build carries (make -C nbody-llm_amd/csrc tuning)");
+#endif
+            if (h->comm_ready && (std::strcmp(name, "cross_sym") == 0 || std::strcmp(name, "sym_packed") == 0 || std::strcmp(name, "bf_fast_variant") == 0))
+                return fail(h, NBODY_ERR_INVALID, std::string("nbody_set_tuning: '") + name + "' is part of what the ranks agreed on at nbody_comm_init: set it before");
+            h->tune.*(k.field) = value;
+            return NBODY_OK;
+        }
+    return fail(h, NBODY_ERR_INVALID, std::string("nbody_set_tuning: unknown knob '") + name + "'");
+}
+
+int nbody_get_tuning(const NbodyHandle* h, const char* name, int* value) {
+    if (!h || !name || !value) return NBODY_ERR_INVALID;
+    for (const Knob& k : kKnobs)
+        if (std::strcmp(k.name, name) == 0) { *value = h->tune.*(k.field); return NBODY_OK; }
+    return NBODY_ERR_INVALID;
+}
+
+int nbody_is_tuning_build(void) {
+#ifdef NBODY_TUNING
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int nbody_comm_transport(const NbodyHandle* h, char* out, size_t cap) {

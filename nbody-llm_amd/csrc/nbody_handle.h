@@ -21,6 +21,7 @@ namespace nbody { namespace let { struct State; } }   // spatial shards (nbody_l
 
 struct NbodyHandle {
     NbodyConfig cfg{};
+    nbody::Tuning tune;        // this handle's launch-shape and scheme knobs (nbody_set_tuning; NBODY_* environment at create)
     int device = 0;
     hipStream_t stream = nullptr;
     Shard sh;

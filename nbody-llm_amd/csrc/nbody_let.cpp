@@ -20,7 +20,6 @@
 #include <algorithm>
 #include <cstring>
 
-extern "C" int nbody_bh_walk_split;
 
 namespace nbody {
 namespace let {

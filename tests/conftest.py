@@ -38,6 +38,34 @@ def gpu(nb):
     return nb
 
 
+@pytest.fixture(scope="session")
+def gpu_tuning(gpu):
+    """The tuning build of the same sources (libnbody_hip_tuning.so: experimental walks, in-kernel stamps), loaded beside the
+    product as a second instance of the mirror.  Built by __graft_entry__.build(); a missing file is a failed build."""
+    nbt = graft.load_package(tuning=True)
+    assert nbt.is_tuning_build() and not gpu.is_tuning_build()
+    return nbt
+
+
+class Knob:
+    """`knob.value = v`: every Simulation created from now on starts with that knob set (the mirror's tuning_defaults without a
+    with-block; the library keeps its knobs per handle: include/nbody_hip.h nbody_set_tuning).  Setting the default removes it."""
+
+    def __init__(self, nb, name, default):
+        self.nb, self.name, self.default = nb, name, default
+
+    @property
+    def value(self):
+        return self.nb._default_tuning.get(self.name, self.default)
+
+    @value.setter
+    def value(self, v):
+        if v == self.default:
+            self.nb._default_tuning.pop(self.name, None)
+        else:
+            self.nb._default_tuning[self.name] = int(v)
+
+
 def particles(orc_or_dtype, pos, vel=None, mass=None):
     dt = orc_or_dtype
     pos = np.asarray(pos, dtype=np.float64)

@@ -28,13 +28,26 @@ def test_library_exports_every_declared_symbol(nb):
 
 
 def test_struct_layouts_match_the_header(nb):
-    # uint32 + 7 x int32 + uint64 + 4 x int32 (48 bytes up to ABI 2, then shard_mode + reserved); 6 x uint64 + 4 x double
+    # uint32 + 7 x int32 + uint64 + 4 x int32 (48 bytes up to ABI 2, then shard_mode + reserved); 6 x uint64 + 4 x double;
+    # NbodyLetStats: 8 x uint64 + 5 x double + 4 x uint64 (ABI 4)
     assert ctypes.sizeof(nb.NbodyConfig) == 56
-    assert ctypes.sizeof(nb.NbodyLetStats) == 104
+    assert ctypes.sizeof(nb.NbodyLetStats) == 136
     assert nb.PARTICLE_DTYPE64.itemsize == 80
     assert ctypes.sizeof(nb.NbodyStats) == 80
     assert nb.PARTICLE_DTYPE.itemsize == 40
     assert [nb.PARTICLE_DTYPE.fields[k][1] for k in ("position", "velocity", "acceleration", "mass")] == [0, 12, 24, 36]
+
+
+def test_library_exports_no_mutable_globals(nb):
+    """Launch-shape knobs live in the handle (nbody_set_tuning); the shared object exports functions only -- no data symbol a
+    second handle, a rank thread or a test could change under a running one."""
+    import subprocess
+    for path in (nb.LIB_PATH, nb.LIB_PATH.replace("libnbody_hip.so", "libnbody_hip_tuning.so")):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        # (what remains in the data sections under the nbody namespace are hipcc's kernel handles, `k_*`: not variables of ours)
+        data = [line for line in out.splitlines()
+                if re.search(r" [BDGSbdgs] nbody_", line) or (re.search(r" [BDGSbdgs] _ZN5nbody", line) and not re.search(r"_ZN5nbody\d+k_", line))]
+        assert not data, data
 
 
 def test_no_device_means_loud_failure(nb):

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import Knob, rel_err
 
 pytestmark = pytest.mark.gpu
 BOX = ((0.0, 0.0, 0.0), 64.0)
@@ -40,7 +40,6 @@ def test_unsynchronised_steps_equal_synchronised_steps(gpu, math, n, box_w, chun
     and build flags stay on the device.  Same kernels, same order: state, counters and elapsed equal the run that
     reads the tree info back every step, bit for bit -- with bodies leaving the box on the way (the walk takes its
     body count from the device) and with the host looking at the count between chunks of steps."""
-    import ctypes
     nb = gpu
     box = ((0.0, 0.0, 0.0), box_w)
     st = nb.Settings(1.0, 0.05, 2e-2 if box_w < 10 else 1e-3, 0.25)
@@ -48,7 +47,7 @@ def test_unsynchronised_steps_equal_synchronised_steps(gpu, math, n, box_w, chun
     mm = nb.FAST if math == "fast" else nb.STRICT
     # fast math: the automatic number of walk segments follows the node count, which the unsynchronised path only
     # bounds from above; another split groups the partial sums differently, so it is pinned here
-    spl = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    spl = Knob(nb, "bh_walk_split", 0)
     spl.value = 4 if n < 1000 else 16
     try:
         a, sa, ea, la = run(nb, ics, box, st, mm, 30, True, chunks)
@@ -75,8 +74,7 @@ def test_poisoned_run_is_replayed_from_the_failed_step(gpu, orc):
     ics = nb.plummer(500, seed=3)
     ics["position"][7] = ics["position"][3] + np.float32(2e-7)
     ics["velocity"][7] = ics["velocity"][3]
-    import ctypes
-    tie = ctypes.c_int.in_dll(nb.lib, "nbody_tree_max_tie")
+    tie = Knob(nb, "tree_max_tie", 64)
     tie.value = 1   # (no second keys: any collision of the 63-bit keys is "too deep", as a group of > 64 would be)
     try:
         a, sa, ea, _ = run(nb, ics, BOX, st, nb.STRICT, 6, True)
@@ -109,10 +107,9 @@ def test_poison_in_the_middle_of_a_run(gpu):
     ics["velocity"][4] = 0.0
     target = ics["position"][4] + np.array([1e-6, 0.0, 0.0], np.float32)   # (never exactly coincident: that is an error)
     ics["velocity"][9] = (target - ics["position"][9]) / np.float32(3.5 * 1e-2)
-    import ctypes
-    spl = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    spl = Knob(nb, "bh_walk_split", 0)
     spl.value = 4
-    tie = ctypes.c_int.in_dll(nb.lib, "nbody_tree_max_tie")
+    tie = Knob(nb, "tree_max_tie", 64)
     tie.value = 1   # (no second keys: the collision poisons the run)
     try:
         a, sa, ea, _ = run(nb, ics, BOX, st, nb.FAST, 10, True)

@@ -259,50 +259,37 @@ def test_fast_symmetric_packed_and_scalar_forms_agree(gpu, orc):
     """k_bf_sym has a packed-fp32 form (two resident bodies per v_pk_* instruction, the default) and a
     scalar one: the same arithmetic per pair, the travelling body's sum split over two halves -- both
     within tolerance of the oracle and within a few ulps of each other."""
-    import ctypes
     nb = gpu
     sd, st = settings(nb, g_soft=1e-2)
     n = 12345
     ics = nb.plummer(n, seed=9)
     ref = ics.copy().astype(orc.P32)
     orc.bf_update_forces_rows(ref, sd, threads=8)
-    packed = ctypes.c_int.in_dll(nb.lib, "nbody_sym_packed")
-    old = packed.value
     accs = {}
-    try:
-        for v in (0, 1):
-            packed.value = v
-            with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
-                sim.settings = st
-                sim.update_forces()
-                accs[v] = sim.get_points()["acceleration"]
-            assert rel_err(accs[v], ref["acceleration"]) < 1e-5, v
-    finally:
-        packed.value = old
+    for v in (0, 1):
+        with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST, tuning=dict(sym_packed=v)) as sim:
+            sim.settings = st
+            sim.update_forces()
+            accs[v] = sim.get_points()["acceleration"]
+        assert rel_err(accs[v], ref["acceleration"]) < 1e-5, v
     assert rel_err(accs[0], accs[1]) < 1e-6
 
 
 def test_fast_every_kernel_variant_agrees(gpu, orc):
     """The 1, 2 and 4 bodies-per-lane instantiations of the LDS-tiled one-sided kernel against the
     oracle, on a size that exercises partial tiles and the self-pair (diagonal) slices."""
-    import ctypes
     nb = gpu
     sd, st = settings(nb)
     n = 5000
     ics = nb.plummer(n, seed=77)
     ref = ics.copy().astype(orc.P32)
     orc.bf_update_forces_rows(ref, sd, threads=8)
-    variant = ctypes.c_int.in_dll(nb.lib, "nbody_bf_fast_variant")
-    try:
-        for v in (1, 2, 4):
-            variant.value = v
-            with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST) as sim:
-                sim.settings = st
-                sim.update_forces()
-                got = sim.get_points()
-            assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5, v
-    finally:
-        variant.value = 0
+    for v in (1, 2, 4):
+        with nb.Simulation(ics, *BOX, method=nb.BRUTE_FORCE, math_mode=nb.FAST, tuning=dict(bf_fast_variant=v)) as sim:
+            sim.settings = st
+            sim.update_forces()
+            got = sim.get_points()
+        assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5, v
 
 
 def test_fast_trajectory_100_steps(gpu, orc):

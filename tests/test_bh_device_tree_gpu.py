@@ -102,23 +102,17 @@ def test_deeper_than_the_device_build_goes_falls_back_to_the_host_build(gpu, orc
     """Two bodies 2e-7 apart in a width-64 box separate only below level 21.  With the device build's second keys
     switched off (nbody_tree_max_tie = 1) it reports "too deep" and the step uses the host build (exact counts);
     coincident bodies raise either way."""
-    import ctypes
     nb = gpu
     sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=0.25)
     ics = nb.plummer(500, seed=3)
     ics["position"][7] = ics["position"][3] + np.float32(2e-7)
     ref = ics.copy().astype(orc.P32)
     acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=2)
-    tie = ctypes.c_int.in_dll(nb.lib, "nbody_tree_max_tie")
-    tie.value = 1
-    try:
-        with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT, tree_build=nb.TREE_DEVICE) as sim:
-            sim.settings = nb.Settings(**sd)
-            sim.update_forces()
-            s = sim.stats()
-            got = sim.get_points()
-    finally:
-        tie.value = 64
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.STRICT, tree_build=nb.TREE_DEVICE, tuning=dict(tree_max_tie=1)) as sim:
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        s = sim.stats()
+        got = sim.get_points()
     assert (s.interactions, s.node_visits) == (acc_n, vis_n)
     assert np.array_equal(got["acceleration"].view(np.uint32), ref["acceleration"].view(np.uint32))
     ics["position"][7] = ics["position"][3]

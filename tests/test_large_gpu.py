@@ -3,7 +3,7 @@ the same kernels at N = 2^20 through size-independent properties and sampled row
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import Knob, rel_err
 
 pytestmark = pytest.mark.gpu
 BOX = ((0.0, 0.0, 0.0), 64.0)
@@ -134,12 +134,11 @@ def test_barnes_hut_four_million_bodies_in_eight_shards(gpu):
     tree from the gathered positions -- here on the device -- and walks it for its own 524 288 bodies;
     eight handles on one device, exchange by device-to-device copies).  Same tree, same per-body walk:
     one step equals the single-handle run bit for bit and the node counts add up exactly."""
-    import ctypes
     nb = gpu
     n, G = 1 << 22, 8
     st = nb.Settings(1.0, 1e-2, 1e-3, 0.25)
     ics = nb.plummer(n, seed=13)
-    split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    split = Knob(nb, "bh_walk_split", 0)
     split.value = 2   # (the default follows the number of own bodies; the sum order of the segments must match)
     try:
         with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as one:

@@ -6,7 +6,7 @@ Oracle of the sharded run = the 1-shard run (and the CPU oracle): strict math bi
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import Knob, rel_err
 
 pytestmark = pytest.mark.gpu
 BOX = ((0.0, 0.0, 0.0), 64.0)
@@ -75,9 +75,8 @@ def test_brute_force_fast_shards(gpu, orc, G, n, cross):
     symmetric kernel; the other shards either symmetric too (cross = 1, the default: every pair
     between shards evaluated once, by one of the two GPUs, partial sums returned to the owner) or
     one-sided (cross = 0, k_bf_os).  1e-5 against the f32 oracle either way."""
-    import ctypes
     nb = gpu
-    ctypes.c_int.in_dll(nb.lib, "nbody_cross_sym").value = cross
+    Knob(nb, "cross_sym", 1).value = cross
     sd = dict(g=1.0, g_soft=1e-2, dt=1e-3, theta2=0.5)
     ics = nb.plummer(n, seed=5)
     ics["mass"] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
@@ -102,13 +101,12 @@ def test_brute_force_fast_shards(gpu, orc, G, n, cross):
         assert all(s_.steps == steps for s_ in st)
     for s in sims:
         s.close()
-    ctypes.c_int.in_dll(nb.lib, "nbody_cross_sym").value = 1
+    Knob(nb, "cross_sym", 1).value = 1
 
 
 def test_cross_shard_pairs_are_dealt_exactly_once(gpu):
     """Host-side plan of the symmetric scheme across shards: over all ranks, every (own set, partner
     chunk) block between two different shards is claimed by exactly one of the two GPUs."""
-    import ctypes
     nb = gpu
     for G in (2, 3, 4, 5, 8):
         n = 4096 * G + 777
@@ -199,9 +197,8 @@ def test_barnes_hut_shards_with_device_tree_equal_single_shard(gpu, G, n, box_w)
     box on the way: per-segment counts, concatenation offsets and own-order lists all move).  The walk's
     node-range split is pinned to 8 segments: its default follows the number of own bodies, and the
     order in which the segments' partial sums are added would differ between the two runs."""
-    import ctypes
     nb = gpu
-    split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+    split = Knob(nb, "bh_walk_split", 0)
     split.value = 8
     box = ((0.0, 0.0, 0.0), box_w)
     st = nb.Settings(1.0, 0.01, 5e-3, 0.25)

@@ -174,7 +174,6 @@ def test_spatial_shards_with_bodies_that_share_all_21_levels(gpu):
     """Groups of bodies a few 1e-7 apart (equal 63-bit keys: always on one rank) get the device build's second keys in
     the distributed build too; without them (nbody_tree_max_tie = 1) the step is refused, there being no host build to
     fall back to."""
-    import ctypes
     nb = gpu
     n, G = 6000, 3
     st = nb.Settings(1.0, 0.01, 1e-3, 0.25)
@@ -195,14 +194,13 @@ def test_spatial_shards_with_bodies_that_share_all_21_levels(gpu):
     assert np.log2(BOX[1] / np.float64(width.min())) > 22
     assert all(s.tree_nodes == s1.tree_nodes for s in stats)
     assert_same_up_to_flips(rec["acceleration"], ref["acceleration"], 2e-6)
-    tie = ctypes.c_int.in_dll(nb.lib, "nbody_tree_max_tie")
-    tie.value = 1
+    for s in sims:
+        s.set_tuning("tree_max_tie", 1)
     try:
         with pytest.raises(nb.NbodyError) as e:
             nb.spatial_step(sims, forces_only=True)
         assert e.value.code == nb.NBODY_ERR_TREE_DEPTH
     finally:
-        tie.value = 64
         close(sims)
 
 

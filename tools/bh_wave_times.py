@@ -4,11 +4,13 @@ import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-nb = graft.load_package()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import knob  # noqa: E402
+nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 splits = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8]
-dbg = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_debug")
-split = ctypes.c_int.in_dll(nb.lib, "nbody_bh_walk_split")
+dbg = knob(nb, "bh_walk_debug")
+split = knob(nb, "bh_walk_split")
 ics = nb.plummer(n)
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE)
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.25)

@@ -4,10 +4,12 @@ import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-nb = graft.load_package()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import knob  # noqa: E402
+nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 splits = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [48]
-g = lambda name: ctypes.c_int.in_dll(nb.lib, name)
+g = lambda name: knob(nb, name)
 dbg, split, var = g("nbody_bh_walk_debug"), g("nbody_bh_walk_split"), g("nbody_bh_walk_variant")
 var.value = int(os.environ.get('VARIANT', '5'))
 ics = nb.plummer(n)

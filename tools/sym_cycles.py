@@ -4,13 +4,15 @@ import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-nb = graft.load_package()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import knob  # noqa: E402
+nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 wps_list = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [12]
 dbg_list = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [4]
 ics = nb.plummer(n)
-wps = ctypes.c_int.in_dll(nb.lib, "nbody_sym_wpb")   # waves per workgroup (16, 12 or 8)
-dbg = ctypes.c_int.in_dll(nb.lib, "nbody_sym_debug")
+wps = knob(nb, "sym_wpb")   # waves per workgroup (16, 12 or 8)
+dbg = knob(nb, "sym_debug")
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST)
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
 for w, dv in [(w, d) for w in wps_list for d in dbg_list]:

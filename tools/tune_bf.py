@@ -3,11 +3,13 @@ rounds; cdna_hip_programming.md rule 24)."""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-nb = graft.load_package()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import knob  # noqa: E402
+nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4]
 ics = nb.plummer(n)
-var = ctypes.c_int.in_dll(nb.lib, "nbody_bf_fast_variant")
+var = knob(nb, "bf_fast_variant")
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST)
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
 res = {v: [] for v in variants}

@@ -4,10 +4,12 @@ table size, workgroup size and node-range split.  Device tree, so the step is no
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-nb = graft.load_package()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import knob  # noqa: E402
+nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ics = nb.plummer(n)
-g = lambda name: ctypes.c_int.in_dll(nb.lib, name)
+g = lambda name: knob(nb, name)
 var, split, cap, blk = g("nbody_bh_walk_variant"), g("nbody_bh_walk_split"), g("nbody_bh_hot_cap"), g("nbody_bh_walk_lds_block")
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE)
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.25)

@@ -11,6 +11,8 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import knob  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("n", nargs="?", type=int, default=65536)
@@ -23,10 +25,10 @@ ap.add_argument("--sym-wpb", default="12", help="own-shard kernel: waves per wor
 ap.add_argument("--sym-rounds", default="1")
 ap.add_argument("--reduce-split", type=int, default=1, help="0: the one-thread-per-body plane reduction of round 1")
 a = ap.parse_args()
-nb = graft.load_package()
-knob = {k: ctypes.c_int.in_dll(nb.lib, f"nbody_cross_{k}") for k in ("ipt", "slots", "wpb")}
-sym_wpb, sym_rounds = ctypes.c_int.in_dll(nb.lib, "nbody_sym_wpb"), ctypes.c_int.in_dll(nb.lib, "nbody_sym_rounds")
-ctypes.c_int.in_dll(nb.lib, "nbody_sym_reduce_split").value = a.reduce_split
+nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
+knob = {k: knob(nb, f"cross_{k}") for k in ("ipt", "slots", "wpb")}
+sym_wpb, sym_rounds = knob(nb, "sym_wpb"), knob(nb, "sym_rounds")
+knob(nb, "sym_reduce_split").value = a.reduce_split
 ics = nb.plummer(a.n)
 for sw, sr in [(int(x), int(y)) for x in a.sym_wpb.split(",") for y in a.sym_rounds.split(",")]:
   sym_wpb.value, sym_rounds.value = sw, sr

@@ -2,14 +2,16 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-nb = graft.load_package()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import knob  # noqa: E402
+nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ics = nb.plummer(n)
-var = ctypes.c_int.in_dll(nb.lib, "nbody_bf_fast_variant")
-wpb = ctypes.c_int.in_dll(nb.lib, "nbody_sym_wpb")
-rounds = ctypes.c_int.in_dll(nb.lib, "nbody_sym_rounds")
-dbg = ctypes.c_int.in_dll(nb.lib, "nbody_sym_debug")
-pk = ctypes.c_int.in_dll(nb.lib, "nbody_sym_packed")
+var = knob(nb, "bf_fast_variant")
+wpb = knob(nb, "sym_wpb")
+rounds = knob(nb, "sym_rounds")
+dbg = knob(nb, "sym_debug")
+pk = knob(nb, "sym_packed")
 sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST)
 sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
 cases = [("sym", 0, w, r, p) for p in (0, 1) for w, r in ((16, 1), (16, 2), (12, 1), (12, 2), (8, 2), (8, 3))]
