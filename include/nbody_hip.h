@@ -182,6 +182,10 @@ int nbody_energy(NbodyHandle* h, double* kinetic, double* potential);
  * index (first node after the subtree, depth-first pre-order).  Arrays may be NULL to count. */
 int nbody_tree_export(NbodyHandle* h, float* com_mass, float* width, int32_t* skip, size_t cap, size_t* n_nodes);
 int nbody_tree_export_f64(NbodyHandle* h, double* com_mass, double* width, int32_t* skip, size_t cap, size_t* n_nodes); /* f64 handles */
+/* The cells of that octree for drawing: what the reference's Barnes-Hut Renderable walks (node.bounds.min() / .max() of
+ * every node, barnes_hut.rs:322-343).  Per node, pre-order: {min xyz, max xyz} as f32 (the renderer casts to f32 anyway,
+ * :331-333; an f64 handle's boxes are computed in double first) and its depth (root = 0).  Arrays may be NULL to count. */
+int nbody_tree_export_cells(NbodyHandle* h, float* min_max6, int32_t* depth, size_t cap, size_t* n_nodes);
 const char* nbody_last_error(const NbodyHandle* h); /* h may be NULL: last create/clone error */
 
 /* ---- launch-shape and scheme knobs of one handle (no reference counterpart) --------------------------------- */

@@ -72,7 +72,7 @@ DECLARED_SYMBOLS = [
     "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
     "nbody_debug_let_bounds", "nbody_debug_let_set_balance",
     "nbody_comm_local_id", "nbody_comm_transport", "nbody_host_exchange_layout",
-    "nbody_set_tuning", "nbody_get_tuning", "nbody_is_tuning_build",
+    "nbody_set_tuning", "nbody_get_tuning", "nbody_is_tuning_build", "nbody_tree_export_cells",
 ]
 
 
@@ -133,6 +133,7 @@ _sig("nbody_stats", _i, _H, C.POINTER(NbodyStats))
 _sig("nbody_reset_stats", _i, _H)
 _sig("nbody_energy", _i, _H, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("nbody_tree_export", _i, _H, C.c_void_p, C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz))
+_sig("nbody_tree_export_cells", _i, _H, C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz))
 _sig("nbody_last_error", C.c_char_p, _H)
 _sig("nbody_comm_unique_id", _i, C.c_void_p)
 _sig("nbody_comm_init", _i, _H, C.c_void_p)
@@ -436,6 +437,15 @@ class Simulation:
         skip = np.zeros(m, np.int32)
         self._check(export(self._h, com.ctypes.data, w.ctypes.data, skip.ctypes.data, m, C.byref(n)))
         return dict(com_mass=com, width=w, skip=skip)
+
+    def tree_cells(self):
+        """(min_max [n, 6] f32, depth [n] i32) of every node of the last tree, pre-order: what the reference's renderer draws."""
+        n = C.c_size_t(0)
+        self._check(lib.nbody_tree_export_cells(self._h, None, None, 0, C.byref(n)))
+        mm = np.zeros((n.value, 6), np.float32)
+        depth = np.zeros(n.value, np.int32)
+        self._check(lib.nbody_tree_export_cells(self._h, mm.ctypes.data, depth.ctypes.data, n.value, C.byref(n)))
+        return mm, depth
 
     def download_ids(self) -> np.ndarray:
         """NBODY_SHARD_SPATIAL: index in the uploaded vector of every body get_points() returns, in the same order."""

@@ -1551,6 +1551,74 @@ int nbody_tree_export_f64(NbodyHandle* h, double* com_mass, double* width, int32
     return nbody64::tree_export(h, com_mass, width, skip, cap, n_nodes);
 }
 
+// ---- the cells of the last tree, for drawing (the reference's Barnes-Hut Renderable walks every node's bounds,
+// barnes_hut.rs:322-343).  The node records carry centre of mass, width and skip link, not the box: it is recovered top
+// down with the reference's own recurrences -- a node's orthant in its parent is get_orthant(parent centre, its centre
+// of mass) (shared.rs:245-254: all its bodies lie in that orthant, so their centre of mass does), its box create_orthant
+// (shared.rs:256-272: centre +- half_width / 2, half_width / 2).
+extern "C++" {
+namespace {
+template <class F>
+void cells_from_preorder(const F* com_mass, const int32_t* skip, size_t n, const F root_center[3], F root_width, float* min_max6, int32_t* depth) {
+    struct Open { size_t end; F c[3]; F half; int depth; };
+    std::vector<Open> stack;
+    for (size_t i = 0; i < n; ++i) {
+        while (!stack.empty() && stack.back().end <= i) stack.pop_back();
+        Open me;
+        me.end = size_t(skip[i]);
+        if (stack.empty()) {
+            for (int k = 0; k < 3; ++k) me.c[k] = root_center[k];
+            me.half = root_width * F(0.5);     // Bounds::new
+            me.depth = 0;
+        } else {
+            const Open& p = stack.back();
+            me.half = p.half * F(0.5);         // create_orthant
+            for (int k = 0; k < 3; ++k) me.c[k] = com_mass[4 * i + k] > p.c[k] ? p.c[k] + me.half : p.c[k] - me.half;
+            me.depth = p.depth + 1;
+        }
+        if (min_max6)
+            for (int k = 0; k < 3; ++k) {
+                min_max6[6 * i + k] = float(me.c[k] + (-me.half));       // Bounds::min (shared.rs:223-225)
+                min_max6[6 * i + 3 + k] = float(me.c[k] + me.half);      // Bounds::max
+            }
+        if (depth) depth[i] = me.depth;
+        if (me.end > i + 1) stack.push_back(me);   // it has children: they follow
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+int nbody_tree_export_cells(NbodyHandle* h, float* min_max6, int32_t* depth, size_t cap, size_t* n_nodes) {
+    if (!h) return NBODY_ERR_INVALID;
+    size_t n = 0;
+    if (h->f64) {
+        int rc = nbody_tree_export_f64(h, nullptr, nullptr, nullptr, 0, &n);
+        if (rc) return rc;
+        if (n_nodes) *n_nodes = n;
+        if (!min_max6 && !depth) return NBODY_OK;
+        if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "tree export buffer too small");
+        std::vector<double> cm(4 * n), w(n);
+        std::vector<int32_t> sk(n);
+        rc = nbody_tree_export_f64(h, cm.data(), w.data(), sk.data(), n, &n);
+        if (rc) return rc;
+        double c[3], width;
+        nbody64::get_bounds(h, c, &width);
+        cells_from_preorder<double>(cm.data(), sk.data(), n, c, width, min_max6, depth);
+        return NBODY_OK;
+    }
+    int rc = nbody_tree_export(h, nullptr, nullptr, nullptr, 0, &n);
+    if (rc) return rc;
+    if (n_nodes) *n_nodes = n;
+    if (!min_max6 && !depth) return NBODY_OK;
+    if (n > cap) return fail(h, NBODY_ERR_CAPACITY, "tree export buffer too small");
+    std::vector<float> cm(4 * n), w(n);
+    std::vector<int32_t> sk(n);
+    rc = nbody_tree_export(h, cm.data(), w.data(), sk.data(), n, &n);
+    if (rc) return rc;
+    cells_from_preorder<float>(cm.data(), sk.data(), n, h->center, h->width, min_max6, depth);
+    return NBODY_OK;
+}
+
 int nbody_comm_unique_id(void* id_bytes) {
     if (!id_bytes) return NBODY_ERR_INVALID;
     // NBODY_TRANSPORT=ipc: ranks that share one device (a one-GPU box rehearsing the multi-rank step); default: RCCL

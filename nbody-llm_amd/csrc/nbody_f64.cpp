@@ -441,6 +441,12 @@ int set_bounds(NbodyHandle* h, const double center[3], double width) {
     return NBODY_OK;
 }
 
+void get_bounds(const NbodyHandle* h, double center[3], double* width) {
+    const State& s = *h->f64;
+    std::memcpy(center, s.center, sizeof(s.center));
+    *width = s.width;
+}
+
 int init(NbodyHandle* h) {
     h->f64->elapsed = 0.0;
     return NBODY_OK;

@@ -15,6 +15,7 @@ int remove_point(NbodyHandle* h, size_t index);
 int set_settings(NbodyHandle* h, double g, double g_soft, double dt, double theta2);
 int get_settings(const NbodyHandle* h, double* g, double* g_soft, double* dt, double* theta2);
 int set_bounds(NbodyHandle* h, const double center[3], double width);
+void get_bounds(const NbodyHandle* h, double center[3], double* width);
 int init(NbodyHandle* h);
 int step_by(NbodyHandle* h, double dt);
 int steps(NbodyHandle* h, int k);

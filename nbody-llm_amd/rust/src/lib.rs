@@ -66,6 +66,8 @@ unsafe extern "C" {
     fn nbody_steps(h: *mut NbodyHandle, k: c_int) -> c_int;
     fn nbody_update_forces(h: *mut NbodyHandle) -> c_int;
     fn nbody_sync(h: *mut NbodyHandle) -> c_int;
+    fn nbody_tree_export_cells(h: *mut NbodyHandle, min_max6: *mut f32, depth: *mut i32, cap: usize, n_nodes: *mut usize) -> c_int;
+    fn nbody_set_tuning(h: *mut NbodyHandle, name: *const c_char, value: c_int) -> c_int;
     fn nbody_last_error(h: *const NbodyHandle) -> *const c_char;
 }
 
@@ -181,6 +183,12 @@ pub struct HipSimulation<F: HipFloat, const METHOD: i32> {
     points_buffer: Option<BufferWrapper>,
     #[cfg(feature = "render")]
     bounds_buffer: Option<BufferWrapper>,
+    /// vertex data of the last frame, reused from frame to frame (positions: 3 per body; boxes: 10 per box)
+    #[cfg(feature = "render")]
+    vertex_scratch: Vec<f32>,
+    /// cells of the last octree as nbody_tree_export_cells delivers them (6 per node) and their depths
+    #[cfg(feature = "render")]
+    cell_scratch: (Vec<f32>, Vec<i32>),
 }
 
 pub type HipBruteForceSimulation<F> = HipSimulation<F, NBODY_BRUTE_FORCE>;
@@ -253,7 +261,18 @@ impl<F: HipFloat, const METHOD: i32> HipSimulation<F, METHOD> {
             points_buffer: None,
             #[cfg(feature = "render")]
             bounds_buffer: None,
+            #[cfg(feature = "render")]
+            vertex_scratch: Vec::new(),
+            #[cfg(feature = "render")]
+            cell_scratch: (Vec::new(), Vec::new()),
         }
+    }
+
+    /// One launch-shape / scheme knob of this handle (include/nbody_hip.h nbody_set_tuning).
+    pub fn set_tuning(&mut self, name: &str, value: i32) {
+        let c = std::ffi::CString::new(name).expect("knob names have no interior NUL");
+        let rc = unsafe { nbody_set_tuning(self.handle, c.as_ptr(), value) };
+        self.check(rc);
     }
 
     /// k x `step()` with no host round trip in between (the headless loop of src/main.rs:119-122).
@@ -304,6 +323,10 @@ impl<F: HipFloat, const METHOD: i32> Clone for HipSimulation<F, METHOD> {
             points_buffer: self.points_buffer.clone(),
             #[cfg(feature = "render")]
             bounds_buffer: self.bounds_buffer.clone(),
+            #[cfg(feature = "render")]
+            vertex_scratch: Vec::new(),
+            #[cfg(feature = "render")]
+            cell_scratch: (Vec::new(), Vec::new()),
         }
     }
 }
@@ -348,11 +371,13 @@ impl<F: HipFloat, const METHOD: i32> Simulation<F, 3, P<F>, I<F>> for HipSimulat
     }
 
     fn get_points(&self) -> &Vec<P<F>> {
-        // SAFETY: single-threaded use (the reference calls its simulation from one thread); the
-        // vector is only replaced here, never while a previously returned borrow can be live
-        // across a &mut self call.
-        let v = unsafe { &mut *self.points.get() };
         if self.dirty.get() {
+            // SAFETY: the exclusive reference lives only inside this branch.  The trait hands out `&Vec` tied to `&self`,
+            // and the device state only becomes newer than the mirror through a `&mut self` call (step, add_point, ...),
+            // which cannot overlap a borrow returned here: when `dirty` is set no shared borrow of the vector exists.
+            // Two overlapping `get_points()` calls (the reference's render loop makes them) both take the shared path
+            // below; forming `&mut` on every call would alias the first borrow.
+            let v: &mut Vec<P<F>> = unsafe { &mut *self.points.get() };
             let mut n: usize = 0;
             let rc = unsafe { nbody_count(self.handle, &mut n) };
             self.check(rc);
@@ -363,7 +388,8 @@ impl<F: HipFloat, const METHOD: i32> Simulation<F, 3, P<F>, I<F>> for HipSimulat
             v.truncate(n);
             self.dirty.set(false);
         }
-        v
+        // SAFETY: shared access; nothing mutates the vector while `dirty` is clear
+        unsafe { &*self.points.get() }
     }
 
     fn elapsed(&self) -> F {
@@ -380,60 +406,102 @@ impl<F: HipFloat, const METHOD: i32> Simulation<F, 3, P<F>, I<F>> for HipSimulat
     }
 }
 
-/// The visualiser's side (src/vis.rs:25-30 wants `Simulation + Renderable`): what
-/// src/manual/brute_force.rs:105-171 does, over the positions synced back on demand by `get_points()`.
+/// The visualiser's side (src/vis.rs:25-30 wants `Simulation + Renderable`).  Same draw calls as the reference's two impls
+/// (src/manual/brute_force.rs:105-171: bodies + the root box; src/manual/barnes_hut.rs:286-374: bodies + EVERY cell of the
+/// octree, coloured by depth), fed from the device: positions through the lazily synced mirror of `get_points()`, cells
+/// through `nbody_tree_export_cells`.  Vertex data is written in one pass into vectors that live across frames.
+#[cfg(feature = "render")]
+impl<F: HipFloat, const METHOD: i32> HipSimulation<F, METHOD> {
+    const FLOATS_PER_BOX: usize = 10; // min xyz, max xyz, rgba: the AABB pipeline's instance layout
+
+    /// 3 f32 per body into `vertex_scratch`; returns the number of bodies.
+    fn stage_positions(&mut self) -> u32 {
+        let mut out = std::mem::take(&mut self.vertex_scratch);
+        out.clear();
+        let pts = self.get_points();
+        out.reserve(3 * pts.len());
+        for p in pts {
+            for x in p.position().iter() {
+                out.push(num_traits::cast::<F, f32>(*x).unwrap());
+            }
+        }
+        let n = pts.len() as u32;
+        self.vertex_scratch = out;
+        n
+    }
+
+    fn push_box(out: &mut Vec<f32>, lo: &[f32], hi: &[f32], rgba: [f32; 4]) {
+        out.extend_from_slice(lo);
+        out.extend_from_slice(hi);
+        out.extend_from_slice(&rgba);
+    }
+
+    /// Boxes to draw into `vertex_scratch`; returns how many.  Brute force: the simulation bounds, green.  Barnes-Hut: the
+    /// cells of the last tree, shaded from coarse to fine with the reference's ramp (barnes_hut.rs:327-336); before the
+    /// first force pass there is no tree and the root box is drawn yellow, as the reference does for `root == None`.
+    fn stage_boxes(&mut self) -> u32 {
+        let mut out = std::mem::take(&mut self.vertex_scratch);
+        out.clear();
+        let root_lo: Vec<f32> = self.bounds.min().iter().map(|x| num_traits::cast::<F, f32>(*x).unwrap()).collect();
+        let root_hi: Vec<f32> = self.bounds.max().iter().map(|x| num_traits::cast::<F, f32>(*x).unwrap()).collect();
+        let mut boxes = 0u32;
+        if METHOD == NBODY_BARNES_HUT {
+            let mut n: usize = 0;
+            let rc = unsafe { nbody_tree_export_cells(self.handle, std::ptr::null_mut(), std::ptr::null_mut(), 0, &mut n) };
+            self.check(rc);
+            if n > 0 {
+                let (cells, depths) = &mut self.cell_scratch;
+                cells.resize(6 * n, 0.0);
+                depths.resize(n, 0);
+                let rc = unsafe { nbody_tree_export_cells(self.handle, cells.as_mut_ptr(), depths.as_mut_ptr(), n, &mut n) };
+                assert_eq!(rc, 0, "nbody_tree_export_cells: {}", last_error(self.handle));
+                let deepest = depths[..n].iter().copied().max().unwrap_or(0).max(1) as f32;
+                out.reserve(Self::FLOATS_PER_BOX * n);
+                for (cell, depth) in cells.chunks_exact(6).zip(depths.iter()).take(n) {
+                    let s = (*depth as f32) / deepest * 0.7 + 0.3;
+                    Self::push_box(&mut out, &cell[..3], &cell[3..], [(1.0 - s * s) * 0.5, s * s, (1.0 - s) * 0.5, s]);
+                }
+                boxes = n as u32;
+            } else {
+                Self::push_box(&mut out, &root_lo, &root_hi, [1.0, 1.0, 0.0, 1.0]);
+                boxes = 1;
+            }
+        } else {
+            Self::push_box(&mut out, &root_lo, &root_hi, [0.0, 1.0, 0.0, 1.0]);
+            boxes = 1;
+        }
+        self.vertex_scratch = out;
+        boxes
+    }
+}
+
 #[cfg(feature = "render")]
 impl<F: HipFloat, const METHOD: i32> Renderable for HipSimulation<F, METHOD> {
     fn render(&mut self, renderer: &mut Renderer) {
-        if self.points_buffer.is_some() {
-            // brute_force.rs:116-125: every position component cast F -> f32, three per body
-            let point_position_data: Vec<f32> = self
-                .get_points()
-                .iter()
-                .flat_map(|p| p.position().iter().map(|x| num_traits::cast::<F, f32>(*x).unwrap()).collect::<Vec<f32>>())
-                .collect();
-            let n_points = (point_position_data.len() / 3) as u32;
-            let points_buffer = self.points_buffer.as_mut().unwrap();
-            points_buffer.update(&renderer.context, point_position_data.as_slice());
-
+        if let Some(mut vb) = self.points_buffer.take() {
+            let bodies = self.stage_positions();
+            vb.update(&renderer.context, self.vertex_scratch.as_slice());
             renderer.set_pipeline(PipelineType::Points);
-            let render_pass = renderer.get_render_pass();
-            render_pass.set_vertex_buffer(0, points_buffer.buffer.slice(..));
-            render_pass.draw(0..4, 0..n_points); // a 4-vertex strip per body (brute_force.rs:132)
+            let pass = renderer.get_render_pass();
+            pass.set_vertex_buffer(0, vb.buffer.slice(..));
+            pass.draw(0..4, 0..bodies); // one 4-vertex strip per body
+            self.points_buffer = Some(vb);
         }
-
-        if let Some(ref mut bounds_buffer) = self.bounds_buffer {
-            // brute_force.rs:135-153: min corner, max corner, colour
-            let mut bounds_data = [self.bounds.min(), self.bounds.max()]
-                .iter()
-                .flat_map(|p| p.iter().map(|x| num_traits::cast::<F, f32>(*x).unwrap()).collect::<Vec<f32>>())
-                .collect::<Vec<f32>>();
-            let color = [0.0, 1.0, 0.0, 1.0];
-            bounds_data.extend(color);
-
-            bounds_buffer.update(&renderer.context, bounds_data.as_slice());
-
+        if let Some(mut vb) = self.bounds_buffer.take() {
+            let boxes = self.stage_boxes();
+            vb.update(&renderer.context, self.vertex_scratch.as_slice());
             renderer.set_pipeline(PipelineType::AABB);
-            let render_pass: &mut wgpu::RenderPass<'_> = renderer.get_render_pass();
-            render_pass.set_vertex_buffer(0, bounds_buffer.buffer.slice(..));
-            render_pass.draw(0..16, 0..1);
+            let pass = renderer.get_render_pass();
+            pass.set_vertex_buffer(0, vb.buffer.slice(..));
+            pass.draw(0..16, 0..boxes); // 16 line vertices per box
+            self.bounds_buffer = Some(vb);
         }
     }
 
     fn render_init(&mut self, context: &Context) {
-        // brute_force.rs:156-170
-        self.points_buffer = Some(BufferWrapper::new(
-            &context.device,
-            Some("Point Buffer"),
-            &[] as &[f32],
-            wgpu::BufferUsages::VERTEX | wgpu::BufferUsages::COPY_DST,
-        ));
-
-        self.bounds_buffer = Some(BufferWrapper::new(
-            &context.device,
-            Some("Bounds Buffer"),
-            &[] as &[f32],
-            wgpu::BufferUsages::VERTEX | wgpu::BufferUsages::COPY_DST,
-        ));
+        let usage = wgpu::BufferUsages::VERTEX | wgpu::BufferUsages::COPY_DST;
+        let empty: &[f32] = &[];
+        self.points_buffer = Some(BufferWrapper::new(&context.device, Some("Point Buffer"), empty, usage));
+        self.bounds_buffer = Some(BufferWrapper::new(&context.device, Some("Bounds Buffer"), empty, usage));
     }
 }

@@ -382,6 +382,16 @@ void linearise(const OrthNode<F>& node, const Body<F>* base, std::vector<F>& com
     skip[me] = int32_t(width.size());
 }
 
+// The cells as the reference's Barnes-Hut renderer walks them (barnes_hut.rs:322-343: node.bounds.min() / .max() of every
+// node), in the pre-order of linearise: 6 values per node.
+template <class F>
+void linearise_cells(const OrthNode<F>& node, std::vector<F>& min_max) {
+    for (int i = 0; i < 3; ++i) min_max.push_back(node.bounds.center[i] + (-node.bounds.half_width));   // Bounds::min, shared.rs:223-225
+    for (int i = 0; i < 3; ++i) min_max.push_back(node.bounds.center[i] + node.bounds.half_width);      // Bounds::max, shared.rs:227-229
+    for (auto& c : node.children)
+        if (c) linearise_cells(*c, min_max);
+}
+
 // f64 diagnostics (not in the reference): KE = Σ ½ m v², PE = −g Σ_{i<j} m_i m_j / sqrt(r²+ε²),
 // the potential whose gradient is the force law of brute_force.rs:72-79.
 template <class F>
@@ -503,6 +513,15 @@ size_t bh_step_by(Body<F>* p, size_t n, const Settings<F>& s, const Box3<F>& box
             std::memcpy(leaf_body, lb.data(), m * sizeof(int32_t));                                            \
         }                                                                                                      \
         return long(m);                                                                                        \
+    }                                                                                                          \
+    extern "C" long oracle_bh_tree_cells_##SFX(const F* aos, size_t n, const F c[3], F w, F* min_max, size_t cap) {\
+        bool too_deep = false;                                                                                 \
+        auto root = build_root((const Body<F>*)aos, n, Box3<F>::make(c, w), 1, &too_deep);                     \
+        if (too_deep) return -2;                                                                               \
+        std::vector<F> mm;                                                                                     \
+        linearise_cells(*root, mm);                                                                            \
+        if (min_max && mm.size() / 6 <= cap) std::memcpy(min_max, mm.data(), mm.size() * sizeof(F));           \
+        return long(mm.size() / 6);                                                                            \
     }                                                                                                          \
     extern "C" void oracle_energy_##SFX(const F* aos, size_t n, double g, double g_soft, int threads,          \
                                         double* ke, double* pe) {                                              \

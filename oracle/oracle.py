@@ -179,6 +179,20 @@ def bh_build_tree(a, center, width) -> dict:
     return dict(com_mass=com, width=w, skip=skip, nchild=nchild, leaf_body=leaf)
 
 
+def bh_tree_cells(a, center, width) -> np.ndarray:
+    """[n_nodes, 6] {min xyz, max xyz} of every node of the reference's tree, pre-order (what its renderer draws)."""
+    s, ct, ft = _sfx(a)
+    fn = getattr(lib(), f"oracle_bh_tree_cells_{s}")
+    fn.restype = C.c_long
+    args = (C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), _arr(ct, center), ct(width))
+    m = fn(*args, None, C.c_size_t(0))
+    if m < 0:
+        raise RuntimeError(f"oracle_bh_tree_cells rc={m}")
+    out = np.zeros((m, 6), ft)
+    fn(*args, C.c_void_p(out.ctypes.data), C.c_size_t(m))
+    return out
+
+
 def energy(a, g=1.0, g_soft=0.0, threads=0):
     """f64 (KE, PE) of a state."""
     s, _, _ = _sfx(a)

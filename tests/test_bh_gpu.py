@@ -238,3 +238,27 @@ def test_full_size_65536_theta_half(gpu, orc):
     assert np.array_equal(t["skip"], rt["skip"])
     assert (s.interactions, s.node_visits) == (acc_n, vis_n)
     assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 300, 5000])
+@pytest.mark.parametrize("mode", ["f32 strict host tree", "f32 fast device tree", "f64 host tree"])
+def test_tree_cells_for_the_renderer_equal_the_references_boxes(gpu, orc, n, mode):
+    """nbody_tree_export_cells: what the reference's Barnes-Hut renderer walks (node.bounds.min()/.max() of every node,
+    barnes_hut.rs:322-343).  The boxes are recovered top down from the linearised tree with the reference's recurrences and
+    equal the oracle's node bounds bit for bit (as f32, which is what the renderer uploads); depths follow the widths."""
+    nb = gpu
+    f64 = mode.startswith("f64")
+    box = ((0.25, -0.5, 0.125), 48.0)
+    ics = nb.plummer(n, seed=400 + n, f64=f64)
+    ref = ics.copy().astype(orc.P64 if f64 else orc.P32)
+    kw = dict(method=nb.BARNES_HUT, math_mode=nb.FAST if "fast" in mode else nb.STRICT,
+              tree_build=nb.TREE_DEVICE if "device" in mode else nb.TREE_HOST)
+    with nb.Simulation(ics, *box, **kw) as sim:
+        sim.settings = nb.Settings(1.0, 0.01, 1e-3, 0.25)
+        sim.update_forces()
+        mm, depth = sim.tree_cells()
+        width = sim.tree()["width"]
+    want = orc.bh_tree_cells(ref, box[0], box[1]).astype(np.float32)
+    assert mm.shape == want.shape
+    assert np.array_equal(mm.view(np.uint32), want.view(np.uint32))
+    assert depth[0] == 0 and np.array_equal(depth, np.round(np.log2(box[1] / width.astype(np.float64))).astype(np.int32))
