@@ -123,7 +123,8 @@ typedef struct NbodyStats {
  * (shared.rs:69-78): g=1, g_soft=0, dt=1e-3, theta2=0.5. */
 int nbody_create(const NbodyConfig* cfg, NbodyHandle** out);
 void nbody_destroy(NbodyHandle* h);
-/* `Clone` supertrait (shared.rs:80; BH clone drops the tree, barnes_hut.rs:113-135). */
+/* `Clone` supertrait (shared.rs:80; BH clone drops the tree, barnes_hut.rs:113-135; the visualiser's reset depends on it,
+ * vis.rs:217-220).  Any handle; the clone of a sharded handle has no communicator: call nbody_comm_init on it. */
 int nbody_clone(const NbodyHandle* h, NbodyHandle** out);
 
 /* ---- state in / out ------------------------------------------------------------------------ */
@@ -137,9 +138,15 @@ int nbody_download(NbodyHandle* h, void* aos, size_t cap, size_t stride_bytes, s
 int nbody_count(NbodyHandle* h, size_t* n_out);
 /* Sum of nbody_count over all ranks as of the last exchange (== nbody_count when world_size == 1). */
 int nbody_count_global(NbodyHandle* h, size_t* n_out);
-/* Simulation::add_point = Vec::push (brute_force.rs:92-94); single-GPU handles only. */
+/* Simulation::add_point = Vec::push (brute_force.rs:92-94).  In a sharded world a COLLECTIVE call (every rank passes the
+ * same particle): the vector is the concatenation of the ranks' blocks, so the body goes to the end of the last rank's
+ * block (NBODY_ERR_CAPACITY when that block is full); with NBODY_SHARD_SPATIAL to the rank that owns its key range, with
+ * the next free index as its place in the vector. */
 int nbody_add_point(NbodyHandle* h, const void* particle);
-/* Simulation::remove_point = Vec::swap_remove (brute_force.rs:96-98); single-GPU handles only. */
+/* Simulation::remove_point = Vec::swap_remove (brute_force.rs:96-98): the world's last body takes the place of body `index`
+ * (an index into the concatenated vector of all ranks; collective in a sharded world -- the body travels between ranks if
+ * they differ).  NBODY_SHARD_SPATIAL: `index` counts the bodies in the order of their indices in the vector, as
+ * nbody_download_ids reports them. */
 int nbody_remove_point(NbodyHandle* h, size_t index);
 
 /* ---- settings: Simulation::settings / settings_mut (shared.rs:95-96) ----------------------- */

@@ -402,7 +402,7 @@ class Simulation:
         rc = lib.nbody_clone(self._h, C.byref(h))
         if rc:
             raise NbodyError(rc, (lib.nbody_last_error(None) or b"").decode())
-        twin = Simulation(None, _handle=h, _f64=self.f64)
+        twin = Simulation(None, rank=self.rank, world_size=self.world_size, _handle=h, _f64=self.f64)
         twin.dtype = self.dtype
         return twin
 

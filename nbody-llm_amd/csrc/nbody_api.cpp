@@ -134,6 +134,87 @@ int comm_check(NbodyHandle* h) {
     return rc ? fail(h, rc, h->tp->error()) : NBODY_OK;
 }
 
+// ---- Vec::push / Vec::swap_remove on a world of index-block shards (collective: every rank makes the same call).
+// The global vector is the concatenation of the ranks' blocks, so push appends to the LAST rank's block and
+// swap_remove(i) moves the world's last body into slot i -- across ranks if they differ (one 40-byte message).
+int sharded_counts_exact(NbodyHandle* h) {   // every rank learns every block's live count
+    if (!h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    int rc = exchange_wait(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    TP_TRY(h, h->tp->all_gather(h->sh.seg_count, sizeof(int), h->stream));
+    h->count_dirty = true;
+    return sync_count(h);
+}
+
+int push_own_count(NbodyHandle* h) {
+    h->h_counts[h->sh.my_seg] = int(h->n_local);
+    HIP_TRY(h, hipMemcpyAsync(h->sh.own_count(), h->h_counts + h->sh.my_seg, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+
+int sharded_add_point(NbodyHandle* h, const void* particle) {
+    int rc = sharded_counts_exact(h);
+    if (rc) return rc;
+    const int G = h->sh.n_seg, last = G - 1;
+    if (total_upper(h) >= h->cfg.capacity || h->seg_count_host[last] >= h->sh.seg_cap)
+        return fail(h, NBODY_ERR_CAPACITY, "capacity exhausted (a push goes to the end of the vector: the last rank's block is full)");
+    if (h->sh.my_seg == last) {
+        const float* p = static_cast<const float*>(particle);
+        float4 rec[3] = {make_float4(p[0], p[1], p[2], p[9]), make_float4(p[3], p[4], p[5], 0.f), make_float4(p[6], p[7], p[8], 0.f)};
+        const size_t k = h->n_local;
+        HIP_TRY(h, hipMemcpyAsync(h->sh.own_pos() + k, &rec[0], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->sh.vel + k, &rec[1], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->sh.acc + k, &rec[2], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->n_local = k + 1;
+        rc = push_own_count(h);
+        if (rc) return rc;
+    }
+    h->seg_count_host[last] += 1;   // (every rank: the bound its grids are sized from; the device copy arrives with the next exchange)
+    return NBODY_OK;
+}
+
+int sharded_remove_point(NbodyHandle* h, size_t index) {
+    int rc = sharded_counts_exact(h);
+    if (rc) return rc;
+    const int G = h->sh.n_seg, me = h->sh.my_seg;
+    if (index >= total_upper(h)) return fail(h, NBODY_ERR_INVALID, "swap_remove index out of range");   // Vec::swap_remove panics
+    int r = 0, last = G - 1;
+    size_t j = index;
+    while (j >= size_t(h->seg_count_host[r])) { j -= size_t(h->seg_count_host[r]); ++r; }
+    while (h->seg_count_host[last] == 0) --last;
+    const size_t tail = size_t(h->seg_count_host[last]) - 1;   // the world's last body: (last, tail)
+    if (r == last) {
+        if (me == r && j != tail) {
+            HIP_TRY(h, hipMemcpyAsync(h->sh.own_pos() + j, h->sh.own_pos() + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->sh.vel + j, h->sh.vel + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->sh.acc + j, h->sh.acc + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+        }
+    } else if (me == last || me == r) {
+        rc = ensure_aos(h, 2);
+        if (rc) return rc;
+        if (me == last) {   // the world's last body as one PointParticle record, to the rank that holds slot `index`
+            nbody::launch_soa_to_aos(h->stream, h->d_aos, 10, 1, h->sh.own_pos() + tail, h->sh.vel + tail, h->sh.acc + tail);
+            TP_TRY(h, h->tp->send(h->d_aos, 40, r, h->stream));
+        } else {
+            TP_TRY(h, h->tp->recv(h->d_aos, 40, last, h->stream));
+            nbody::launch_aos_to_soa(h->stream, h->d_aos, 10, 1, h->sh.own_pos() + j, h->sh.vel + j, h->sh.acc + j);
+        }
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (me == last) {
+        h->n_local = tail;
+        rc = push_own_count(h);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->seg_count_host[last] -= 1;
+    return comm_check(h);
+}
+
 struct ForceTimer {  // HIP events around a force-kernel launch, on the launch stream
     NbodyHandle* h;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -1102,7 +1183,6 @@ void nbody_destroy(NbodyHandle* h) { free_all(h); }
 int nbody_clone(const NbodyHandle* src, NbodyHandle** out) {
     if (!src || !out) return fail(nullptr, NBODY_ERR_INVALID, "null argument");
     NbodyHandle* s = const_cast<NbodyHandle*>(src);
-    if (src->let) return fail(nullptr, NBODY_ERR_INVALID, "nbody_clone is not supported on NBODY_SHARD_SPATIAL handles");
     int rc = use_device(s);
     if (rc) return rc;
     rc = resolve_async(s);
@@ -1139,6 +1219,10 @@ int nbody_clone(const NbodyHandle* src, NbodyHandle** out) {
     h->n_local = src->n_local;
     h->seg_count_host = src->seg_count_host;
     h->first_global = src->first_global; h->n_at_upload = src->n_at_upload;
+    if (src->let) {   // spatial shards: + the bodies' ids and the ownership bounds
+        rc = nbody::let::clone_state(s, h);
+        if (rc) { g_create_err = h->err; free_all(h); return rc; }
+    }
     // like the reference's BH clone (barnes_hut.rs:113-135) the tree is not carried over; neither
     // are the communicator (call nbody_comm_init on the clone) and the statistics
     *out = h;
@@ -1234,10 +1318,11 @@ int nbody_count_global(NbodyHandle* h, size_t* n_out) {
 
 int nbody_add_point(NbodyHandle* h, const void* particle) {
     if (!h || !particle) return NBODY_ERR_INVALID;
-    if (h->sh.n_seg != 1 || h->let) return fail(h, NBODY_ERR_INVALID, "add_point is only supported on single-GPU handles");
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::add_point(h, particle);
+    if (h->let) return nbody::let::add_point(h, particle);
+    if (h->sh.n_seg != 1) return sharded_add_point(h, particle);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);
@@ -1257,10 +1342,11 @@ int nbody_add_point(NbodyHandle* h, const void* particle) {
 
 int nbody_remove_point(NbodyHandle* h, size_t index) {
     if (!h) return NBODY_ERR_INVALID;
-    if (h->sh.n_seg != 1 || h->let) return fail(h, NBODY_ERR_INVALID, "remove_point is only supported on single-GPU handles");
     int rc = use_device(h);
     if (rc) return rc;
     if (h->f64) return nbody64::remove_point(h, index);
+    if (h->let) return nbody::let::remove_point(h, index);
+    if (h->sh.n_seg != 1) return sharded_remove_point(h, index);
     rc = resolve_async(h);
     if (rc) return rc;
     rc = sync_count(h);

@@ -77,6 +77,7 @@ struct State {
     int* h_pred_pin = nullptr;    // pinned staging of d_pred
     Migrant* d_slot_out = nullptr;   // the packed emigrants again, one slot of pred[me][r] records per destination
     size_t slot_out_cap = 0;
+    long long count_delta = 0;    // bodies pushed / removed since the last pass (count_global reads the last pass's table)
     uint64_t spills = 0;          // steps that had to make their migrant round twice
     uint64_t host_syncs = 0;      // host synchronisations inside passes (NbodyLetStats.host_syncs)
     uint64_t node_array_peak = 0; // most node records this rank held at once: own slice + imports
@@ -465,7 +466,172 @@ int count_global(NbodyHandle* h, size_t* n_out) {
     HIP_TRY(h, hipMemcpy(e.data(), s.d_ends, sizeof(EndInfo) * s.G, hipMemcpyDeviceToHost));
     size_t t = 0;
     for (const EndInfo& x : e) t += size_t(std::max(0, x.n_bodies));
-    *n_out = t;
+    *n_out = size_t(std::max<long long>(0, (long long)t + s.count_delta));
+    return NBODY_OK;
+}
+
+// ---- Clone / Vec::push / Vec::swap_remove on spatial shards (include/nbody_hip.h) -----------------------------------
+int clone_state(NbodyHandle* src, NbodyHandle* dst) {
+    State& a = *src->let;
+    State& b = *dst->let;
+    HIP_TRY(src, hipStreamSynchronize(src->stream));
+    const size_t cap = size_t(src->sh.seg_cap);
+    HIP_TRY(dst, hipMemcpyAsync(dst->sh.ids, src->sh.ids, cap * sizeof(int), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d_bounds, a.d_bounds, (size_t(a.G) + 1) * sizeof(unsigned long long), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d_ends, a.d_ends, size_t(a.G) * sizeof(EndInfo), hipMemcpyDeviceToDevice, dst->stream));   // (count_global reads it)
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    b.h_bounds = a.h_bounds;
+    b.prune = a.prune; b.rebalance = a.rebalance; b.by_work = a.by_work;
+    b.count_delta = a.count_delta;
+    b.have_pred = false;
+    return NBODY_OK;
+}
+
+namespace {
+// exact own count + the own ids on the host (ascending copy in `sorted`)
+int fetch_ids(NbodyHandle* h, std::vector<int>& ids, std::vector<int>& sorted) {
+    Shard& sh = h->sh;
+    HIP_TRY(h, hipMemcpyAsync(h->h_counts, sh.seg_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_local = size_t(h->h_counts[0]); h->seg_count_host[0] = int(h->n_local); h->count_dirty = false;
+    ids.resize(h->n_local);
+    if (h->n_local) HIP_TRY(h, hipMemcpy(ids.data(), sh.ids, h->n_local * sizeof(int), hipMemcpyDeviceToHost));
+    sorted = ids;
+    std::sort(sorted.begin(), sorted.end());
+    return NBODY_OK;
+}
+// one number from every rank (host side; a world of one without a communicator is just itself)
+int gather_ll(NbodyHandle* h, long long mine, std::vector<long long>& all) {
+    State& s = *h->let;
+    all.assign(size_t(s.G), 0);
+    if (!h->comm_ready) {
+        if (s.G > 1) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+        all[0] = mine;
+        return NBODY_OK;
+    }
+    TP_TRY(h, h->tp->host_all_gather(&mine, all.data(), sizeof(long long)));
+    return NBODY_OK;
+}
+int push_count(NbodyHandle* h) {
+    h->h_counts[0] = int(h->n_local);
+    h->seg_count_host[0] = int(h->n_local);
+    HIP_TRY(h, hipMemcpyAsync(h->sh.seg_count, h->h_counts, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NBODY_OK;
+}
+}  // namespace
+
+// Vec::push: the body goes to the rank whose key range holds it; its place in the vector is the next free index
+int add_point(NbodyHandle* h, const void* particle) {
+    State& s = *h->let;
+    Shard& sh = h->sh;
+    if (!h->bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+    std::vector<int> ids, sorted;
+    int rc = fetch_ids(h, ids, sorted);
+    if (rc) return rc;
+    std::vector<long long> tops;
+    rc = gather_ll(h, sorted.empty() ? -1LL : (long long)sorted.back(), tops);
+    if (rc) return rc;
+    const long long id = *std::max_element(tops.begin(), tops.end()) + 1;
+    std::vector<unsigned long long> bounds(size_t(s.G) + 1);
+    HIP_TRY(h, hipMemcpy(bounds.data(), s.d_bounds, bounds.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const float* p = static_cast<const float*>(particle);
+    const unsigned long long key = host_key(p, h->center, h->width);
+    int owner = 0;
+    for (int r = 1; r < s.G; ++r) if (bounds[size_t(r)] <= key) owner = r;
+    long long ok = 1;
+    if (owner == s.me) {
+        if (h->n_local >= size_t(sh.seg_cap)) ok = 0;
+        else {
+            float4 rec[3] = {make_float4(p[0], p[1], p[2], p[9]), make_float4(p[3], p[4], p[5], 0.f), make_float4(p[6], p[7], p[8], 0.f)};
+            const int id32 = int(id);
+            const size_t k = h->n_local;
+            HIP_TRY(h, hipMemcpyAsync(sh.own_pos() + k, &rec[0], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sh.vel + k, &rec[1], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sh.acc + k, &rec[2], sizeof(float4), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sh.ids + k, &id32, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            h->n_local = k + 1;
+            rc = push_count(h);
+            if (rc) return rc;
+        }
+    }
+    std::vector<long long> oks;   // every rank returns the same verdict
+    rc = gather_ll(h, ok, oks);
+    if (rc) return rc;
+    if (*std::min_element(oks.begin(), oks.end()) == 0) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: the rank that owns the new body's key range is full");
+    s.count_delta += 1;
+    return NBODY_OK;
+}
+
+// Vec::swap_remove(index): `index` counts the world's bodies in the order of their indices in the vector; the body with
+// the largest index takes the removed one's place (its index), as the reference's last element does
+int remove_point(NbodyHandle* h, size_t index) {
+    State& s = *h->let;
+    Shard& sh = h->sh;
+    std::vector<int> ids, sorted;
+    int rc = fetch_ids(h, ids, sorted);
+    if (rc) return rc;
+    std::vector<long long> all;
+    rc = gather_ll(h, (long long)sorted.size(), all);
+    if (rc) return rc;
+    long long total = 0;
+    for (long long c : all) total += c;
+    if ((long long)index >= total) return fail(h, NBODY_ERR_INVALID, "swap_remove index out of range");
+    rc = gather_ll(h, sorted.empty() ? -1LL : (long long)sorted.back(), all);
+    if (rc) return rc;
+    const long long top = *std::max_element(all.begin(), all.end());
+    // the (index+1)-th smallest id of the world: bisection on the value, one count from every rank per round
+    long long lo = 0, hi = top;
+    while (lo < hi) {
+        const long long mid = lo + (hi - lo) / 2;
+        const long long mine = (long long)(std::upper_bound(sorted.begin(), sorted.end(), int(mid)) - sorted.begin());
+        rc = gather_ll(h, mine, all);
+        if (rc) return rc;
+        long long below = 0;
+        for (long long c : all) below += c;
+        if (below >= (long long)index + 1) hi = mid; else lo = mid + 1;
+    }
+    const int victim = int(lo);
+    // the world's last body takes the victim's index
+    if (victim != int(top)) {
+        auto it = std::find(ids.begin(), ids.end(), int(top));
+        if (it != ids.end()) {
+            const size_t at = size_t(it - ids.begin());
+            HIP_TRY(h, hipMemcpy(sh.ids + at, &victim, sizeof(int), hipMemcpyHostToDevice));
+            ids[at] = victim;   // (if this rank also holds the victim, the search below must find the ORIGINAL: see the index guard)
+            auto vit = std::find(ids.begin(), ids.end(), victim);
+            if (vit != ids.end() && size_t(vit - ids.begin()) == at) vit = std::find(vit + 1, ids.end(), victim);
+            if (vit != ids.end()) {
+                const size_t j = size_t(vit - ids.begin()), tail = h->n_local - 1;
+                if (j != tail) {
+                    HIP_TRY(h, hipMemcpyAsync(sh.own_pos() + j, sh.own_pos() + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+                    HIP_TRY(h, hipMemcpyAsync(sh.vel + j, sh.vel + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+                    HIP_TRY(h, hipMemcpyAsync(sh.acc + j, sh.acc + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+                    HIP_TRY(h, hipMemcpyAsync(sh.ids + j, sh.ids + tail, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+                }
+                h->n_local = tail;
+                rc = push_count(h);
+                if (rc) return rc;
+            }
+            s.count_delta -= 1;
+            return NBODY_OK;
+        }
+    }
+    auto vit = std::find(ids.begin(), ids.end(), victim);
+    if (vit != ids.end()) {
+        const size_t j = size_t(vit - ids.begin()), tail = h->n_local - 1;
+        if (j != tail) {
+            HIP_TRY(h, hipMemcpyAsync(sh.own_pos() + j, sh.own_pos() + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sh.vel + j, sh.vel + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sh.acc + j, sh.acc + tail, sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sh.ids + j, sh.ids + tail, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->n_local = tail;
+        rc = push_count(h);
+        if (rc) return rc;
+    }
+    s.count_delta -= 1;
     return NBODY_OK;
 }
 
@@ -542,6 +708,7 @@ static int account(NbodyHandle* h, State& s) {
     s.st.bytes_sent += sent * sizeof(LetRecord);
     s.node_array_peak = std::max<uint64_t>(s.node_array_peak, uint64_t(std::max(0, s.h_pin[2 * s.G * s.G + s.G + 1])) + rec);
     if (h->profiling) collect_phase_times(s, s.ev_set);
+    s.count_delta = 0;
     return NBODY_OK;
 }
 
@@ -727,6 +894,7 @@ static int pass(NbodyHandle* h, float dt, bool is_step) {
     rc = phase4(h, s, dt, is_step);
     if (rc) return rc;
     s.ev_set ^= 1;   // (the next pass records into the other set; this one's are read once they have completed)
+    s.count_delta = 0;   // (the table count_global reads is this pass's)
     return NBODY_OK;
 }
 

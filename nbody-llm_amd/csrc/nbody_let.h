@@ -13,6 +13,9 @@ void destroy(NbodyHandle* h);
 int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride);   // every rank passes the full vector
 int download_ids(NbodyHandle* h, int32_t* ids, size_t cap, size_t* n_out);
 int count_global(NbodyHandle* h, size_t* n_out);
+int clone_state(NbodyHandle* src, NbodyHandle* dst);    // ids, ownership bounds (the communicator is re-attached by nbody_comm_init)
+int add_point(NbodyHandle* h, const void* particle);    // collective
+int remove_point(NbodyHandle* h, size_t index);         // collective
 int step(NbodyHandle* h, float dt);         // one step with the RCCL exchanges
 int update_forces(NbodyHandle* h);
 int stats(NbodyHandle* h, NbodyLetStats* out);

@@ -65,10 +65,24 @@ def make_sim(nb, cfg: dict, points: np.ndarray, rank: int, world: int, device: i
         shard_mode=nb.SHARD_SPATIAL if sim_cfg.get("shard", "index") == "spatial" else nb.SHARD_INDEX)
 
 
-def run_schedule(nb, sim, schedule) -> None:
+def run_schedule(nb, sim, schedule, reattach=None):
+    """Runs the schedule; returns the simulation it ended with (a "clone" entry replaces it by its clone, whose communicator
+    `reattach(clone)` sets up again -- nbody_clone does not carry one over)."""
     for item in schedule:
         op = item[0]
-        if op == "steps":
+        if op == "add_point":        # [x, y, z, vx, vy, vz, mass]: Vec::push (collective in a sharded world)
+            p = np.zeros(1, nb.PARTICLE_DTYPE)
+            p["position"], p["velocity"], p["mass"] = item[1][:3], item[1][3:6], item[1][6]
+            sim.add_point(p)
+        elif op == "remove_point":   # Vec::swap_remove
+            sim.remove_point(int(item[1]))
+        elif op == "clone":
+            twin = sim.clone()
+            if reattach is not None:
+                reattach(twin)
+            sim.close()
+            sim = twin
+        elif op == "steps":
             sim.steps(int(item[1]))
         elif op == "step_by":
             sim.step_by(float(item[1]))
@@ -80,6 +94,7 @@ def run_schedule(nb, sim, schedule) -> None:
             sim.sync()
         else:
             raise ValueError(f"unknown schedule entry {item}")
+    return sim
 
 
 def _rank_main(cfg: dict, rank: int, failed: list) -> None:
@@ -98,8 +113,13 @@ def _rank_main(cfg: dict, rank: int, failed: list) -> None:
         sim.comm_init(ident)
         sim.init()
         rdzv.barrier()
+
+        def reattach(twin):
+            twin.rank, twin.world_size = rank, world
+            twin.comm_init(rdzv.bcast_bytes((nb.comm_local_id() if ipc else nb.comm_unique_id()) if rank == 0 else None))
+
         t0 = time.perf_counter()
-        run_schedule(nb, sim, cfg["schedule"])
+        sim = run_schedule(nb, sim, cfg["schedule"], reattach)
         sim.sync()
         wall = time.perf_counter() - t0
         pts = sim.get_points()

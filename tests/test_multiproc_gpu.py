@@ -34,7 +34,7 @@ def single(nb, cfg, **kw):
     with ranks.make_sim(nb, one, pts, 0, 1, 0) as sim:
         sim.settings = nb.Settings(**cfg["settings"])
         sim.init()
-        ranks.run_schedule(nb, sim, cfg["schedule"])
+        sim = ranks.run_schedule(nb, sim, cfg["schedule"])
         return sim.get_points(), sim.stats()
 
 
@@ -174,6 +174,52 @@ def test_spatial_step_repeats_its_migrant_round_when_the_posted_sizes_do_not_hol
     assert sum(r["let"]["bodies_migrated"] for r in res) > 500
     for r in res:
         assert r["let"]["host_syncs"] == 5 + 1 + r["let"]["migrant_respills"]
+
+
+EDITS = [["steps", 2], ["add_point", [0.3, -0.2, 0.1, 0.0, 0.4, 0.0, 2e-3]], ["steps", 1], ["remove_point", 5], ["steps", 1], ["clone"],
+         ["remove_point", 1499], ["add_point", [-0.5, 0.5, 0.25, 0.1, 0.0, -0.1, 1e-3]], ["add_point", [0.05, 0.0, -0.3, 0.0, 0.0, 0.2, 1e-3]],
+         ["remove_point", 700], ["steps", 2]]
+
+
+@pytest.mark.parametrize("G,method,math", [(3, "bf", "strict"), (2, "bh", "strict"), (4, "bf", "fast")])
+def test_trait_surface_on_index_block_ranks_push_swap_remove_clone(gpu, tmp_path, G, method, math):
+    """Simulation::add_point = Vec::push, remove_point = Vec::swap_remove, Clone (src/shared.rs:80,91-92; the visualiser uses all
+    three, src/vis.rs:217-251) on a world of index-block ranks: collective calls, the vector being the concatenation of the
+    ranks' blocks (a push lands in the last rank's block, swap_remove moves the world's last body across ranks).  The world
+    equals the one-handle run of the same schedule -- strict math: bit for bit."""
+    nb = gpu
+    from nbody_llm_amd import ranks
+    sd = dict(g=1.0, g_soft=0.02, dt=2e-3, theta2=0.25)
+    cfg = world_cfg(tmp_path, G, dict(method=method, math=math, capacity=1600), dict(n=1500, seed=71), sd, EDITS)
+    res = launch(cfg, G)
+    got = ranks.gather_world(res)
+    ref, _ = single(nb, cfg)
+    assert len(got) == len(ref) == 1500
+    assert sum(r["count"] for r in res) == res[0]["count_global"] == 1500
+    if math == "strict":
+        for f in FIELDS:
+            assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    else:
+        assert np.array_equal(got["mass"], ref["mass"])
+        assert rel_err(got["position"], ref["position"]) < 1e-6 and rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
+
+
+def test_trait_surface_on_spatial_ranks_push_swap_remove_clone(gpu, tmp_path):
+    """The same on spatial shards: a pushed body goes to the rank that owns its key range and takes the next free index of the
+    vector; swap_remove(i) removes the body with the i-th index and hands its index to the world's last one; a clone carries
+    the bodies, their indices and the ownership bounds."""
+    nb = gpu
+    from nbody_llm_amd import ranks
+    sd = dict(g=1.0, g_soft=0.02, dt=2e-3, theta2=0.25)
+    cfg = world_cfg(tmp_path, 3, dict(method="bh", math="fast", shard="spatial", capacity=1600), dict(n=1500, seed=71), sd, EDITS)
+    res = launch(cfg, 3)
+    got = ranks.gather_world(res)
+    ref, _ = single(nb, cfg, tree="device")
+    assert len(got) == len(ref) == 1500 and sum(r["count"] for r in res) == res[0]["count_global"] == 1500
+    assert sorted(np.concatenate([r["ids"] for r in res]).tolist()) == list(range(1500))     # the indices stay those of a Vec of 1500
+    assert np.array_equal(got["mass"], ref["mass"])
+    assert np.abs(got["position"].astype(np.float64) - ref["position"]).max() < 2e-6
+    assert_same_up_to_flips(got["acceleration"], ref["acceleration"], 1e-5)
 
 
 def test_ranks_created_unlike_fail_at_comm_init_instead_of_hanging(gpu, tmp_path):

@@ -305,10 +305,13 @@ def test_spatial_handles_refuse_what_they_do_not_support(gpu):
         with pytest.raises(nb.NbodyError) as e:
             sim.step()                      # no communicator
         assert e.value.code == nb.NBODY_ERR_COMM
-        with pytest.raises(nb.NbodyError):
-            sim.add_point(ics[0])
-        with pytest.raises(nb.NbodyError):
-            sim.clone()
+        with pytest.raises(nb.NbodyError) as e:
+            sim.add_point(ics[0])           # collective: needs the communicator too
+        assert e.value.code == nb.NBODY_ERR_COMM
+        twin = sim.clone()                  # Clone is a supertrait of Simulation (shared.rs:80): bodies, indices, bounds
+        assert np.array_equal(twin.get_points(), sim.get_points()) and np.array_equal(twin.download_ids(), sim.download_ids())
+        assert np.array_equal(twin.let_bounds(), sim.let_bounds())
+        twin.close()
         for call in (sim.tree, sim.energy):   # a spatial rank holds neither the whole tree nor all bodies: no silent partial answers
             with pytest.raises(nb.NbodyError) as e:
                 call()
