@@ -74,11 +74,13 @@ enum {
 
 /* the reference's `F: Float` (src/shared.rs:12-44) */
 enum { NBODY_F32 = 0,  /* PointParticle<f32,3>: every path of this library */
-       NBODY_F64 = 1 }; /* PointParticle<f64,3>: one shard, strict arithmetic (math_mode is ignored).  Barnes-Hut with the
-                          host build (NBODY_TREE_HOST, also what AUTO means here): positions, velocities, accelerations
-                          and node counts bit-equal to the reference's rounding sequence in f64 (oracle/: the same
-                          templated restatement); with NBODY_TREE_DEVICE the tree is built on the device (same cells,
-                          centres of mass to the last bits: node counts within 1e-6), ~4x the steps per second */
+       NBODY_F64 = 1 }; /* PointParticle<f64,3> (80-byte records).  Brute force: the strict kernel.  Barnes-Hut, NBODY_MATH_STRICT: the
+                          reference's nested sums on the host-built tree (NBODY_TREE_HOST, also what AUTO means then): positions,
+                          velocities, accelerations and node counts bit-equal to the reference's rounding sequence in f64 (oracle/:
+                          the same templated restatement); with NBODY_TREE_DEVICE the tree is built on the device (same cells, centres
+                          of mass to the last bits: node counts within 1e-6), ~4x the steps per second.  NBODY_MATH_FAST: one running
+                          sum per lane (FMA, 1/sqrt) over a split node range, device build under AUTO: accelerations to 1e-12.
+                          Worlds of several ranks: index-block shards (strict results bit-equal to one shard), tree built on the host */
 
 /* how the bodies are dealt to the shards of a multi-GPU run */
 enum { NBODY_SHARD_INDEX = 0,   /* contiguous index blocks of the vector; positions all-gathered every step (every method) */

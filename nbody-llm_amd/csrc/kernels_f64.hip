@@ -23,6 +23,13 @@ __global__ __launch_bounds__(256) void k_aos_to_soa(const double* __restrict__ a
     acc[k] = make_double4(p[6], p[7], p[8], 0.0);
 }
 
+__global__ __launch_bounds__(256) void k_aos_to_pos(const double* __restrict__ aos, int stride_d, int n, double4* __restrict__ pos) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double* p = aos + size_t(k) * stride_d;
+    pos[k] = make_double4(p[0], p[1], p[2], p[9]);
+}
+
 __global__ __launch_bounds__(256) void k_soa_to_aos(double* __restrict__ aos, int stride_d, int n, const double4* __restrict__ pos,
                                                     const double4* __restrict__ vel, const double4* __restrict__ acc) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -138,31 +145,41 @@ __global__ __launch_bounds__(kTile) void k_compact(double4* __restrict__ pos, do
 constexpr int kStrictBlock = 256;
 constexpr int kStrictTile = 512;   // 16 KB of LDS
 
-__global__ __launch_bounds__(kStrictBlock) void k_bf_strict(const double4* __restrict__ pos, const int* __restrict__ count,
-                                                            double4* __restrict__ acc, double g, double eps2,
+__global__ __launch_bounds__(kStrictBlock) void k_bf_strict(const double4* __restrict__ pos_all, const int* __restrict__ seg_count, int n_seg,
+                                                            int seg_cap, int my_seg, double4* __restrict__ acc, double g, double eps2,
                                                             unsigned long long* __restrict__ inter) {
     __shared__ double4 tile[kStrictTile];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kStrictBlock + tid;
-    const int n = *count;
-    if (inter && blockIdx.x == 0 && tid == 0 && n > 0) atomicAdd(inter, (unsigned long long)n * (unsigned long long)(n - 1));
-    const double4 pi = (i < n) ? pos[i] : make_double4(0.0, 0.0, 0.0, 0.0);
+    const int n = seg_count[my_seg];
+    if (inter && blockIdx.x == 0 && tid == 0 && n > 0) {
+        long long tot = 0;
+        for (int sg = 0; sg < n_seg; ++sg) tot += seg_count[sg];
+        atomicAdd(inter, (unsigned long long)n * (unsigned long long)(tot - 1));
+    }
+    const double4 pi = (i < n) ? pos_all[size_t(my_seg) * seg_cap + i] : make_double4(0.0, 0.0, 0.0, 0.0);
     double ax = 0.0, ay = 0.0, az = 0.0;  // :65-67
-    for (int t0 = 0; t0 < n; t0 += kStrictTile) {
-        const int cnt = min(kStrictTile, n - t0);
-        __syncthreads();
-        for (int k = tid; k < cnt; k += kStrictBlock) tile[k] = pos[t0 + k];
-        __syncthreads();
-        for (int j = 0; j < cnt; ++j) {
-            if (t0 + j == i) continue;  // the reference never forms the i == j pair (:70-71)
-            const double4 pj = tile[j];
-            const double rx = pi.x - pj.x, ry = pi.y - pj.y, rz = pi.z - pj.z;   // :72
-            const double r_dist = __builtin_sqrt((rx * rx + ry * ry) + rz * rz + eps2);  // :73
-            const double r_cubed = r_dist * r_dist * r_dist;                      // :74
-            const double force = (g / r_cubed);                                    // :77
-            ax -= (rx * force) * pj.w;                                             // :78
-            ay -= (ry * force) * pj.w;
-            az -= (rz * force) * pj.w;
+    // partners in ascending GLOBAL index: the blocks in rank order, each in its own order (a G-shard run adds in the
+    // one-shard run's order: bit-equal)
+    for (int sg = 0; sg < n_seg; ++sg) {
+        const double4* __restrict__ pos = pos_all + size_t(sg) * seg_cap;
+        const int m = seg_count[sg];
+        for (int t0 = 0; t0 < m; t0 += kStrictTile) {
+            const int cnt = min(kStrictTile, m - t0);
+            __syncthreads();
+            for (int k = tid; k < cnt; k += kStrictBlock) tile[k] = pos[t0 + k];
+            __syncthreads();
+            for (int j = 0; j < cnt; ++j) {
+                if (sg == my_seg && t0 + j == i) continue;  // the reference never forms the i == j pair (:70-71)
+                const double4 pj = tile[j];
+                const double rx = pi.x - pj.x, ry = pi.y - pj.y, rz = pi.z - pj.z;   // :72
+                const double r_dist = __builtin_sqrt((rx * rx + ry * ry) + rz * rz + eps2);  // :73
+                const double r_cubed = r_dist * r_dist * r_dist;                      // :74
+                const double force = (g / r_cubed);                                    // :77
+                ax -= (rx * force) * pj.w;                                             // :78
+                ay -= (ry * force) * pj.w;
+                az -= (rz * force) * pj.w;
+            }
         }
     }
     if (i < n) acc[i] = make_double4(ax, ay, az, 0.0);
@@ -280,6 +297,71 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_direct(const Node64* __r
     add_counts(counters, n_acc, n_vis);
 }
 
+// ---- K5, fast arithmetic: the opening tests are the reference's (same products, same comparison: node counts stay
+// exact on the host-built tree), the accepted monopoles are added into one running sum per lane with FMAs and 1/sqrt
+__device__ __forceinline__ int walk_entry64(const Node64* __restrict__ nodes, const WalkSplit64& sp, int seg, const double4 p, double theta2, bool direct) {
+    const int na = sp.n_anc[seg];
+    for (int k = 0; k < na; ++k) {
+        const Node64 nd = nodes[sp.anc[seg * kMaxAnc64 + k]];
+        const double rx = nd.x - p.x, ry = nd.y - p.y, rz = nd.z - p.z;
+        const double r2 = (rx * rx + ry * ry) + rz * rz;
+        if (direct && r2 < 1e-10) return nd.skip;
+        if (nd.w2 < theta2 * r2) return nd.skip;   // accepted: the walk resumes after its subtree
+    }
+    return sp.first[seg];
+}
+
+template <bool DIRECT>
+__global__ __launch_bounds__(kWalkBlock) void k_bh_walk_fast64(const Node64* __restrict__ nodes, int n_nodes, const int* __restrict__ order, int n_order,
+                                                               const double4* __restrict__ pos, double4* __restrict__ acc, double g, double eps2,
+                                                               double theta2, unsigned long long* __restrict__ counters, WalkSplit64 split) {
+    const int t = blockIdx.x * kWalkBlock + threadIdx.x;
+    // a body group's long walks are in the segments around its own place in the tree: those first (kernels_bh.hip k_bh_walk)
+    const int K = gridDim.y;
+    const int diag = int((long long)blockIdx.x * K / gridDim.x);
+    const int kk = blockIdx.y;
+    const int seg = ((diag + ((kk & 1) ? (kk + 1) / 2 : -(kk / 2))) % K + K) % K;
+    const int s1 = split.first[seg + 1];
+    unsigned int n_acc = 0, n_vis = 0;
+    if (t < n_order) {
+        const int b = order[t];
+        const double4 p = pos[b];
+        double ax = 0.0, ay = 0.0, az = 0.0;
+        int i = walk_entry64(nodes, split, seg, p, theta2, DIRECT);
+        while (i < s1) {
+            const Node64 nd = nodes[i];
+            const double rx = nd.x - p.x, ry = nd.y - p.y, rz = nd.z - p.z;
+            const double r2 = (rx * rx + ry * ry) + rz * rz;
+            const int skip = nd.skip;
+            ++n_vis;
+            if (DIRECT && r2 < 1e-10) { i = skip; continue; }
+            if (nd.w2 < theta2 * r2 || (DIRECT && skip == i + 1)) {
+                const double rinv = rsqrt(r2 + eps2);
+                const double k = (g * nd.m) * ((rinv * rinv) * rinv);
+                ax = fma(rx, k, ax); ay = fma(ry, k, ay); az = fma(rz, k, az);
+                ++n_acc;
+                i = skip;
+            } else {
+                i = i + 1;
+            }
+        }
+        *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) = make_double4(ax, ay, az, 0.0);
+    }
+    add_counts(counters, n_acc, n_vis);
+}
+
+__global__ __launch_bounds__(256) void k_bh_reduce64(const double4* __restrict__ planes, int n_seg, size_t plane_stride, const int* __restrict__ order,
+                                                     int n_order, double4* __restrict__ acc) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_order) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int k = 0; k < n_seg; ++k) {   // segment order = the order the single walk adds them in
+        const double4 v = planes[size_t(k) * plane_stride + t];
+        sx += v.x; sy += v.y; sz += v.z;
+    }
+    acc[order[t]] = make_double4(sx, sy, sz, 0.0);
+}
+
 // ---- diagnostics: KE and pair-potential row sums, per-block partials {KE, sum_j m_i m_j / d_ij}
 constexpr int kEnergyBlock = 256;
 __global__ __launch_bounds__(kEnergyBlock) void k_energy(const double4* __restrict__ pos, const double4* __restrict__ vel,
@@ -322,6 +404,10 @@ void launch_aos_to_soa(hipStream_t s, const double* aos, int stride_d, int n, co
     if (n <= 0) return;
     hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks_for(n, 256)), dim3(256), 0, s, aos, stride_d, n, d.pos + first, d.vel + first, d.acc + first);
 }
+void launch_aos_to_pos(hipStream_t s, const double* aos, int stride_d, int n, double4* pos) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_aos_to_pos, dim3(blocks_for(n, 256)), dim3(256), 0, s, aos, stride_d, n, pos);
+}
 void launch_soa_to_aos(hipStream_t s, double* aos, int stride_d, int n, const Dev& d) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(n, 256)), dim3(256), 0, s, aos, stride_d, n, d.pos, d.vel, d.acc);
@@ -341,7 +427,8 @@ void launch_kick_drift(hipStream_t s, const Dev& d, int n_upper, double dt) {
 }
 void launch_bf_strict(hipStream_t s, const Dev& d, int n_upper, double g, double eps2) {
     if (n_upper <= 0) return;
-    hipLaunchKernelGGL(k_bf_strict, dim3(blocks_for(n_upper, kStrictBlock)), dim3(kStrictBlock), 0, s, d.pos, d.count, d.acc, g, eps2, d.inter);
+    hipLaunchKernelGGL(k_bf_strict, dim3(blocks_for(n_upper, kStrictBlock)), dim3(kStrictBlock), 0, s, d.pos_all, d.seg_count, d.n_seg, d.cap, d.my_seg,
+                       d.acc, g, eps2, d.inter);
 }
 void launch_bh_walk(hipStream_t s, const Dev& d, const Node64* nodes, int n_nodes, const int* order, int n_order, double g, double eps2,
                     double theta2, unsigned long long* counters, int leaf_direct, Open64* stack, size_t stack_stride) {
@@ -352,6 +439,17 @@ void launch_bh_walk(hipStream_t s, const Dev& d, const Node64* nodes, int n_node
     else
         hipLaunchKernelGGL(k_bh_walk_nested, grid, dim3(kWalkBlock), 0, s, nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters,
                            stack, stack_stride);
+}
+void launch_bh_walk_fast(hipStream_t s, const Dev& d, const Node64* nodes, int n_nodes, const int* order, int n_order, double g, double eps2,
+                         double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split) {
+    if (n_order <= 0) return;
+    const dim3 grid(blocks_for(n_order, kWalkBlock), split.n_seg);
+    if (leaf_direct)
+        hipLaunchKernelGGL(k_bh_walk_fast64<true>, grid, dim3(kWalkBlock), 0, s, nodes, n_nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters, split);
+    else
+        hipLaunchKernelGGL(k_bh_walk_fast64<false>, grid, dim3(kWalkBlock), 0, s, nodes, n_nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters, split);
+    if (split.n_seg > 1)
+        hipLaunchKernelGGL(k_bh_reduce64, dim3(blocks_for(n_order, 256)), dim3(256), 0, s, split.planes, split.n_seg, split.plane_stride, order, n_order, d.acc);
 }
 void launch_energy(hipStream_t s, const Dev& d, int n_upper, double eps2, double* out2) {
     if (n_upper <= 0) return;

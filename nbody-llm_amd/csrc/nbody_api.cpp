@@ -1032,7 +1032,8 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, NBODY_ERR_INVALID, "bad rank/world_size");
     if (cfg->capacity == 0 || cfg->capacity > (1ull << 30)) return fail(nullptr, NBODY_ERR_INVALID, "capacity must be in [1, 2^30]");
     if (cfg->dtype != NBODY_F32 && cfg->dtype != NBODY_F64) return fail(nullptr, NBODY_ERR_INVALID, "unknown dtype");
-    if (cfg->dtype == NBODY_F64 && cfg->world_size != 1) return fail(nullptr, NBODY_ERR_INVALID, "f64 handles are single-shard (world_size must be 1)");
+    if (cfg->dtype == NBODY_F64 && cfg->world_size != 1 && cfg->shard_mode != NBODY_SHARD_INDEX)
+        return fail(nullptr, NBODY_ERR_INVALID, "f64 worlds are sharded by index blocks (NBODY_SHARD_INDEX)");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1048,9 +1049,13 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
     h->cfg = *cfg;
     if (h->cfg.tree_build == NBODY_TREE_AUTO)   // the bit-exact path keeps the reference's (host) build
         h->cfg.tree_build = cfg->math_mode == NBODY_MATH_FAST ? NBODY_TREE_DEVICE : NBODY_TREE_HOST;
-    if (h->cfg.dtype == NBODY_F64) {   // what F = f64 runs: the strict kernels; the reference's exact tree unless the device build is asked for
-        if (h->cfg.tree_build != NBODY_TREE_DEVICE) h->cfg.tree_build = NBODY_TREE_HOST;
-        h->cfg.math_mode = NBODY_MATH_STRICT;
+    if (h->cfg.dtype == NBODY_F64) {
+        // F = f64: brute force always runs the strict kernel; Barnes-Hut strict = the reference's nested sums on the host-built
+        // tree (bit-exact) unless the device build is asked for, fast = one running sum per lane over a split node range, on
+        // the device-built tree unless the host build is asked for (AUTO: as for f32)
+        if (cfg->method == NBODY_BRUTE_FORCE) h->cfg.math_mode = NBODY_MATH_STRICT;
+        if (cfg->tree_build == NBODY_TREE_AUTO) h->cfg.tree_build = h->cfg.math_mode == NBODY_MATH_FAST ? NBODY_TREE_DEVICE : NBODY_TREE_HOST;
+        if (cfg->world_size > 1) h->cfg.tree_build = NBODY_TREE_HOST;   // (a sharded f64 world builds the replicated tree on the host)
     }
     if (h->cfg.shard_mode == NBODY_SHARD_SPATIAL) h->cfg.tree_build = NBODY_TREE_DEVICE;
     cfg = &h->cfg;
@@ -1073,8 +1078,8 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
             CREATE_TRY(hipMemsetAsync(h->d_counters, 0, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), h->stream));
             CREATE_TRY(hipHostMalloc(&h->h_counters, 2 * NBODY_WALK_COUNTER_SLOTS * sizeof(unsigned long long), hipHostMallocDefault));
         }
-        h->sh.n_seg = 1; h->sh.my_seg = 0; h->sh.seg_cap = int(cfg->capacity);
-        h->seg_count_host.assign(1, 0);
+        h->sh.n_seg = cfg->world_size; h->sh.my_seg = cfg->rank; h->sh.seg_cap = int((cfg->capacity + cfg->world_size - 1) / cfg->world_size);
+        h->seg_count_host.assign(size_t(cfg->world_size), 0);
         int rc64 = nbody64::create(h);
         if (rc64) return bail(rc64);
         *out = h;
@@ -1306,7 +1311,7 @@ int nbody_count_global(NbodyHandle* h, size_t* n_out) {
     if (!h || !n_out) return NBODY_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
-    if (h->f64) return nbody64::count(h, n_out);
+    if (h->f64) return nbody64::count_global(h, n_out);
     if (h->let) return nbody::let::count_global(h, n_out);
     rc = resolve_async(h);
     if (rc) return rc;
@@ -1734,7 +1739,6 @@ static const char* const kAgreementFields[] = {"ABI version", "method", "math_mo
 
 int nbody_comm_init(NbodyHandle* h, const void* id_bytes) {
     if (!h || !id_bytes) return NBODY_ERR_INVALID;
-    if (h->f64) return fail(h, NBODY_ERR_INVALID, "f64 handles are single-shard");
     int rc = use_device(h);
     if (rc) return rc;
     h->comm_ready = false;

@@ -1,7 +1,10 @@
 // nbody_f64.cpp -- host orchestration of an F = f64 handle: the reference's `Simulation<f64, 3, PointParticle<f64,3>, _>`
-// (the instantiation its own driver uses, src/main.rs:52-105).  One shard, strict arithmetic, the octree built on the
-// host in f64 (octree_host.cpp, the same stable 8-way partition as for f32): positions, velocities, accelerations
-// and node counts equal the oracle's f64 instantiation bit for bit.  Bodies cross the boundary as 80-byte records.
+// (the instantiation its own driver uses, src/main.rs:52-105).  Strict arithmetic with the octree built on the host in f64
+// (octree_host.cpp, the same stable 8-way partition as for f32): positions, velocities, accelerations and node counts
+// equal the oracle's f64 instantiation bit for bit -- on one shard and over index-block shards alike (the blocks'
+// positions and live counts are exchanged once per step through the handle's transport; partners and tree bodies keep
+// their global order).  NBODY_MATH_FAST: the fast walk (one running sum per lane, split node range), device build on one
+// shard.  Bodies cross the boundary as 80-byte records.
 #include "nbody_f64.h"
 #include "kernels_f64.h"
 
@@ -22,7 +25,9 @@ struct State {
     double elapsed = 0.0;
     size_t n_local = 0;        // host view of the body count (an upper bound while count_dirty)
     bool count_dirty = false;
-    int* h_count = nullptr;    // pinned [2]
+    int* h_count = nullptr;    // pinned [n_seg + 1]: the blocks' live counts
+    std::vector<int> count_upper;   // host bound of every block's live count (counts only shrink between uploads)
+    std::vector<int> own_order;
     double* d_aos = nullptr;   // staging for PointParticle<f64,3> records
     double* h_aos = nullptr;   // pinned
     size_t aos_cap = 0;
@@ -47,6 +52,11 @@ struct State {
     nbody::TreeDevWork tree_work;
     bool tree_on_device = false;  // where the last tree lives (nbody_tree_export)
     size_t dev_nodes = 0;
+    // fast walk (NBODY_MATH_FAST): node-range split points and the segments' partial sums
+    int* d_split = nullptr;       // [kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc64] first[], n_anc[], anc[][]
+    int* h_split = nullptr;       // pinned mirror (host-built tree)
+    double4* d_planes = nullptr;  // [K][cap]
+    size_t planes_cap = 0;
 };
 
 namespace {
@@ -86,16 +96,18 @@ int ensure_aos(NbodyHandle* h, State& s, size_t records) {
 
 int sync_count(NbodyHandle* h, State& s) {
     if (!s.count_dirty) return NBODY_OK;
-    HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.seg_count, sizeof(int) * s.d.n_seg, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    s.n_local = size_t(s.h_count[0]);
+    for (int g = 0; g < s.d.n_seg; ++g) s.count_upper[size_t(g)] = s.h_count[g];
+    s.n_local = size_t(s.h_count[s.d.my_seg]);
     s.count_dirty = false;
     return NBODY_OK;
 }
 
 int push_count(NbodyHandle* h, State& s) {
-    s.h_count[0] = int(s.n_local);
-    HIP_TRY(h, hipMemcpyAsync(s.d.count, s.h_count, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    s.h_count[s.d.n_seg] = int(s.n_local);
+    s.count_upper[size_t(s.d.my_seg)] = int(s.n_local);
+    HIP_TRY(h, hipMemcpyAsync(s.d.count, s.h_count + s.d.n_seg, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NBODY_OK;
 }
@@ -123,7 +135,11 @@ int bf_forces(NbodyHandle* h, State& s) {
         launch_bf_strict(h->stream, s.d, int(s.n_local), s.g, eps2);
     }
     HIP_TRY(h, hipGetLastError());
-    if (h->profiling && s.n_local > 0) h->stats.force_kernel_interactions += uint64_t(s.n_local) * uint64_t(s.n_local - 1);
+    if (h->profiling && s.n_local > 0) {
+        uint64_t tot = 0;
+        for (int c : s.count_upper) tot += uint64_t(c);
+        h->stats.force_kernel_interactions += uint64_t(s.n_local) * (tot - 1);
+    }
     return NBODY_OK;
 }
 
@@ -136,6 +152,60 @@ int ensure_stack(NbodyHandle* h, State& s, int levels) {   // the nested sums' s
         HIP_TRY(h, hipMalloc(&s.d_stack, lanes * size_t(lv) * sizeof(Open64)));
         s.stack_lanes = lanes; s.stack_levels = lv;
     }
+    return NBODY_OK;
+}
+
+// The fast walk (NBODY_MATH_FAST on an f64 handle): one running sum per lane, node range split over K segments so that a
+// few ten thousand bodies still fill the chip.  `host_nodes` != nullptr: the split points' ancestors are listed here from
+// the host-built tree; nullptr: by k_tree_split_anc from the device build's arrays (n_tree bodies).
+constexpr int kMaxSplit = 64;
+int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const int* order, int n_order, const nbody::NodeRecT<double>* host_nodes, int n_tree) {
+    constexpr size_t kSplitInts = kMaxSplit + 1 + kMaxSplit + size_t(kMaxSplit) * kMaxAnc64;
+    if (!s.d_split) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_split), kSplitInts * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.h_split), kSplitInts * sizeof(int), hipHostMallocDefault));
+    }
+    const size_t groups = std::max<size_t>(1, (size_t(n_order) + 63) / 64);
+    int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + groups - 1) / groups);
+    K = std::max(1, std::min(kMaxSplit, K));
+    while (nbody::tuning().bh_walk_split <= 0 && K > 1 && K * 16 > n_nodes) K /= 2;
+    if (n_order == 0 || n_nodes <= 0) return NBODY_OK;
+    int* first = s.d_split;
+    int* n_anc = s.d_split + kMaxSplit + 1;
+    int* anc = s.d_split + kMaxSplit + 1 + kMaxSplit;
+    if (host_nodes) {
+        int* hf = s.h_split;
+        int* hn = hf + kMaxSplit + 1;
+        int* ha = hn + kMaxSplit;
+        for (int k = 0; k <= K; ++k) hf[k] = int((long long)n_nodes * k / K);
+        for (int k = 0; k < K; ++k) {   // ancestors of first[k]: down from the root along the skip links
+            int cnt = 0, j = 0;
+            const int target = hf[k];
+            while (j != target && cnt < kMaxAnc64) {
+                ha[k * kMaxAnc64 + cnt++] = j;
+                int c = j + 1;
+                while (host_nodes[c].b.skip <= target) c = host_nodes[c].b.skip;
+                j = c;
+            }
+            hn[k] = cnt;
+        }
+        HIP_TRY(h, hipMemcpyAsync(s.d_split, s.h_split, (kMaxSplit + 1 + kMaxSplit + size_t(K) * kMaxAnc64) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    } else {
+        nbody::launch_tree_split_anc(h->stream, s.tree_work, n_tree, n_nodes, K, first, n_anc, anc, kMaxAnc64);
+    }
+    if (K > 1 && size_t(K) * size_t(s.d.cap) > s.planes_cap) {
+        if (s.d_planes) (void)hipFree(s.d_planes);
+        s.d_planes = nullptr; s.planes_cap = 0;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_planes), size_t(K) * size_t(s.d.cap) * sizeof(double4)));
+        s.planes_cap = size_t(K) * size_t(s.d.cap);
+    }
+    WalkSplit64 sp{K, first, anc, n_anc, s.d_planes, size_t(s.d.cap)};
+    {
+        ForceTimer t(h);
+        launch_bh_walk_fast(h->stream, s.d, nodes, n_nodes, order, n_order, s.g, s.g_soft * s.g_soft, s.theta2, h->d_counters,
+                            h->cfg.leaf_mode == NBODY_LEAF_DIRECT ? 1 : 0, sp);
+    }
+    HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
 
@@ -187,6 +257,7 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
     s.tree_on_device = true;
     h->stats.tree_build_ms += ms_since(t0);
     h->stats.tree_nodes = s.dev_nodes;
+    if (h->cfg.math_mode == NBODY_MATH_FAST) return fast_walk(h, s, s.d_nodes, int(s.dev_nodes), s.d_order, int(s.n_local), nullptr, int(s.n_local));
     const bool direct = h->cfg.leaf_mode == NBODY_LEAF_DIRECT;
     if (!direct) { int rc = ensure_stack(h, s, 45); if (rc) return rc; }   // (the device build goes to 42 levels)
     {
@@ -200,23 +271,40 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
 
 // BarnesHutSimulation::update_forces (barnes_hut.rs:250-263): rebuild the tree (host, f64), one walk per body
 int bh_forces(NbodyHandle* h, State& s) {
-    if (h->cfg.tree_build == NBODY_TREE_DEVICE) {
+    if (h->cfg.tree_build == NBODY_TREE_DEVICE && s.d.n_seg == 1) {   // (a sharded f64 world builds on the host: create says so)
         bool fell_back = false;
         int rc = bh_forces_device(h, s, &fell_back);
         if (rc || !fell_back) return rc;
     }
     s.tree_on_device = false;
     auto t0 = clk::now();
-    if (s.n_local) HIP_TRY(h, hipMemcpyAsync(s.h_pos, s.d.pos, s.n_local * sizeof(double4), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    const int G = s.d.n_seg;
+    for (int g = 0; g < G; ++g) {   // every block's positions (upper-bound counts) + the live counts, one synchronisation
+        const size_t cnt = size_t(s.count_upper[size_t(g)]);
+        if (cnt) HIP_TRY(h, hipMemcpyAsync(s.h_pos + 4 * size_t(g) * s.d.cap, s.d.pos_all + size_t(g) * s.d.cap, cnt * sizeof(double4), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.seg_count, sizeof(int) * G, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    s.n_local = size_t(s.h_count[0]);
+    for (int g = 0; g < G; ++g) s.count_upper[size_t(g)] = s.h_count[g];
+    s.n_local = size_t(s.h_count[s.d.my_seg]);
     s.count_dirty = false;
     const double copy_ms = ms_since(t0);
     auto t1 = clk::now();
-    int cnt = int(s.n_local);
-    nbody::build_octree<double>(s.h_pos, 1, s.d.cap, &cnt, s.center, s.width, *h->pool, s.scratch, s.tree);
+    nbody::build_octree<double>(s.h_pos, G, s.d.cap, s.h_count, s.center, s.width, *h->pool, s.scratch, s.tree);
     if (s.tree.too_deep) return fail(h, NBODY_ERR_TREE_DEPTH, "octree deeper than NBODY_MAX_TREE_DEPTH (coincident bodies?)");
+    // the own bodies in tree order (ids are block * cap + index in the block)
+    const int32_t* order = s.tree.order;
+    size_t n_order = s.tree.n_order;
+    if (G > 1) {
+        s.own_order.clear();
+        const int lo = s.d.my_seg * s.d.cap, hi = lo + s.d.cap;
+        for (size_t k = 0; k < s.tree.n_order; ++k) {
+            const int id = s.tree.order[k];
+            if (id >= lo && id < hi) s.own_order.push_back(id - lo);
+        }
+        order = s.own_order.data();
+        n_order = s.own_order.size();
+    }
     h->stats.tree_build_ms += ms_since(t1);
     h->stats.tree_nodes = s.tree.n_nodes;
     auto t2 = clk::now();
@@ -227,22 +315,25 @@ int bh_forces(NbodyHandle* h, State& s) {
         HIP_TRY(h, hipMalloc(&s.d_nodes, cap * sizeof(Node64)));
         s.node_cap = cap;
     }
-    if (s.tree.n_order > s.order_cap) {
+    if (n_order > s.order_cap) {
         if (s.d_order) (void)hipFree(s.d_order);
         s.d_order = nullptr; s.order_cap = 0;
-        const size_t cap = s.tree.n_order + s.tree.n_order / 4 + 1024;
+        const size_t cap = n_order + n_order / 4 + 1024;
         HIP_TRY(h, hipMalloc(&s.d_order, cap * sizeof(int)));
         s.order_cap = cap;
     }
     static_assert(sizeof(nbody::NodeRecT<double>) == sizeof(Node64), "host and device node records must agree");
     HIP_TRY(h, hipMemcpyAsync(s.d_nodes, s.tree.nodes, s.tree.n_nodes * sizeof(Node64), hipMemcpyHostToDevice, h->stream));
-    if (s.tree.n_order) HIP_TRY(h, hipMemcpyAsync(s.d_order, s.tree.order, s.tree.n_order * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (n_order) HIP_TRY(h, hipMemcpyAsync(s.d_order, order, n_order * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (G > 1) HIP_TRY(h, hipStreamSynchronize(h->stream));   // own_order is pageable and reused
     h->stats.tree_copy_ms += copy_ms + ms_since(t2);
+    if (h->cfg.math_mode == NBODY_MATH_FAST)
+        return fast_walk(h, s, s.d_nodes, int(s.tree.n_nodes), s.d_order, int(n_order), s.tree.nodes, int(s.tree.n_order));
     const bool direct = h->cfg.leaf_mode == NBODY_LEAF_DIRECT;
     if (!direct) { int rc = ensure_stack(h, s, s.tree.max_depth + 2); if (rc) return rc; }   // the tree's depth
     {
         ForceTimer t(h);
-        launch_bh_walk(h->stream, s.d, s.d_nodes, int(s.tree.n_nodes), s.d_order, int(s.tree.n_order), s.g, s.g_soft * s.g_soft, s.theta2,
+        launch_bh_walk(h->stream, s.d, s.d_nodes, int(s.tree.n_nodes), s.d_order, int(n_order), s.g, s.g_soft * s.g_soft, s.theta2,
                        h->d_counters, direct ? 1 : 0, s.d_stack, s.stack_lanes);
     }
     HIP_TRY(h, hipGetLastError());
@@ -251,13 +342,27 @@ int bh_forces(NbodyHandle* h, State& s) {
 
 int forces(NbodyHandle* h, State& s) { return h->cfg.method == NBODY_BARNES_HUT ? bh_forces(h, s) : bf_forces(h, s); }
 
+// index-block shards: the once-per-step exchange, in place, on the handle's stream
+int exchange(NbodyHandle* h, State& s) {
+    if (s.d.n_seg == 1 && !h->comm_ready) return NBODY_OK;
+    if (!h->comm_ready) return fail(h, NBODY_ERR_COMM, "world_size > 1 but nbody_comm_init has not been called");
+    int rc = h->tp->group_begin();
+    if (!rc) rc = h->tp->all_gather(s.d.pos_all, size_t(s.d.cap) * sizeof(double4), h->stream);
+    if (!rc) rc = h->tp->all_gather(s.d.seg_count, sizeof(int), h->stream);
+    if (!rc) rc = h->tp->group_end();
+    if (rc) return fail(h, rc, "f64 exchange: " + h->tp->error());
+    return NBODY_OK;
+}
+
 int step_impl(NbodyHandle* h, State& s, double dt) {
     if (!s.bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
     launch_drift_half(h->stream, s.d, int(s.n_local), dt, s.bnd);   // integrate_pre_force
     launch_compact(h->stream, s.d, int(s.n_local));                 // retain
     s.count_dirty = true;
     HIP_TRY(h, hipGetLastError());
-    int rc = forces(h, s);                                          // update_forces
+    int rc = exchange(h, s);                                        // sharded: every block's positions and live count
+    if (rc) return rc;
+    rc = forces(h, s);                                              // update_forces
     if (rc) return rc;
     launch_kick_drift(h->stream, s.d, int(s.n_local), dt);          // integrate_after_force
     HIP_TRY(h, hipGetLastError());
@@ -272,33 +377,39 @@ int create(NbodyHandle* h) {
     State* sp = new State();
     h->f64 = sp;
     State& s = *sp;
-    const size_t cap = size_t(h->cfg.capacity);
+    const int G = h->cfg.world_size;
+    const size_t cap = (size_t(h->cfg.capacity) + size_t(G) - 1) / size_t(G);   // bodies a block can hold
     s.d.cap = int(cap);
-    HIP_TRY(h, hipMalloc(&s.d.pos, cap * sizeof(double4)));
+    s.d.n_seg = G;
+    s.d.my_seg = h->cfg.rank;
+    s.count_upper.assign(size_t(G), 0);
+    HIP_TRY(h, hipMalloc(&s.d.pos_all, size_t(G) * cap * sizeof(double4)));
+    s.d.pos = s.d.pos_all + size_t(s.d.my_seg) * cap;
     HIP_TRY(h, hipMalloc(&s.d.vel, cap * sizeof(double4)));
     HIP_TRY(h, hipMalloc(&s.d.acc, cap * sizeof(double4)));
-    HIP_TRY(h, hipMalloc(&s.d.count, sizeof(int)));
+    HIP_TRY(h, hipMalloc(&s.d.seg_count, sizeof(int) * G));
+    s.d.count = s.d.seg_count + s.d.my_seg;
     HIP_TRY(h, hipMalloc(&s.d.escaped, sizeof(int)));
     HIP_TRY(h, hipMalloc(&s.d.keep, cap));
     const size_t tiles = (cap + 1023) / 1024 + 1;
     HIP_TRY(h, hipMalloc(&s.d.tile_state, tiles * sizeof(unsigned long long)));
     HIP_TRY(h, hipMalloc(&s.d.epoch, sizeof(int)));
     HIP_TRY(h, hipMalloc(&s.d.inter, sizeof(unsigned long long)));
-    HIP_TRY(h, hipMemsetAsync(s.d.pos, 0, cap * sizeof(double4), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.pos_all, 0, size_t(G) * cap * sizeof(double4), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d.vel, 0, cap * sizeof(double4), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d.acc, 0, cap * sizeof(double4), h->stream));
-    HIP_TRY(h, hipMemsetAsync(s.d.count, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(s.d.seg_count, 0, sizeof(int) * G, h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d.escaped, 0, sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d.keep, 1, cap, h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d.tile_state, 0, tiles * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d.epoch, 0, sizeof(int), h->stream));
     HIP_TRY(h, hipMemsetAsync(s.d.epoch, 1, 1, h->stream));   // epoch = 1
     HIP_TRY(h, hipMemsetAsync(s.d.inter, 0, sizeof(unsigned long long), h->stream));
-    HIP_TRY(h, hipHostMalloc(&s.h_count, 2 * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&s.h_count, (size_t(G) + 1) * sizeof(int), hipHostMallocDefault));
     if (h->cfg.method == NBODY_BARNES_HUT) {
         s.tree.alloc = pinned_alloc;
         s.tree.release = pinned_free;
-        HIP_TRY(h, hipHostMalloc(&s.h_pos, cap * sizeof(double4), hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc(&s.h_pos, size_t(G) * cap * sizeof(double4), hipHostMallocDefault));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NBODY_OK;
@@ -308,10 +419,10 @@ void destroy(NbodyHandle* h) {
     State* s = h->f64;
     if (!s) return;
     s->tree.clear();
-    void* dev[] = {s->d.pos, s->d.vel, s->d.acc, s->d.count, s->d.escaped, s->d.keep, s->d.tile_state, s->d.epoch, s->d.inter,
-                   s->d_aos, s->d_nodes, s->d_order, s->d_stack, s->d_energy, s->d_tree_ws, s->d_tree_info};
+    void* dev[] = {s->d.pos_all, s->d.vel, s->d.acc, s->d.seg_count, s->d.escaped, s->d.keep, s->d.tile_state, s->d.epoch, s->d.inter,
+                   s->d_aos, s->d_nodes, s->d_order, s->d_stack, s->d_energy, s->d_tree_ws, s->d_tree_info, s->d_split, s->d_planes};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {s->h_count, s->h_aos, s->h_pos, s->h_tree_info};
+    void* host[] = {s->h_count, s->h_aos, s->h_pos, s->h_tree_info, s->h_split};
     for (void* p : host) if (p) (void)hipHostFree(p);
     delete s;
     h->f64 = nullptr;
@@ -324,10 +435,11 @@ int clone_state(NbodyHandle* src, NbodyHandle* dst) {
     if (rc) return rc;
     const size_t cap = size_t(a.d.cap);
     HIP_TRY(dst, hipStreamSynchronize(src->stream));
-    HIP_TRY(dst, hipMemcpyAsync(b.d.pos, a.d.pos, cap * sizeof(double4), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d.pos_all, a.d.pos_all, size_t(a.d.n_seg) * cap * sizeof(double4), hipMemcpyDeviceToDevice, dst->stream));
     HIP_TRY(dst, hipMemcpyAsync(b.d.vel, a.d.vel, cap * sizeof(double4), hipMemcpyDeviceToDevice, dst->stream));
     HIP_TRY(dst, hipMemcpyAsync(b.d.acc, a.d.acc, cap * sizeof(double4), hipMemcpyDeviceToDevice, dst->stream));
-    HIP_TRY(dst, hipMemcpyAsync(b.d.count, a.d.count, sizeof(int), hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(b.d.seg_count, a.d.seg_count, sizeof(int) * a.d.n_seg, hipMemcpyDeviceToDevice, dst->stream));
+    b.count_upper = a.count_upper;
     HIP_TRY(dst, hipStreamSynchronize(dst->stream));
     b.g = a.g; b.g_soft = a.g_soft; b.dt = a.dt; b.theta2 = a.theta2;
     std::memcpy(b.center, a.center, sizeof(b.center));
@@ -340,18 +452,31 @@ int clone_state(NbodyHandle* src, NbodyHandle* dst) {
 int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride) {
     State& s = *h->f64;
     if (stride < 80 || stride % 8) return fail(h, NBODY_ERR_INVALID, "f64 handle: stride must be a multiple of 8 and >= 80 bytes");
-    if (n > size_t(s.d.cap)) return fail(h, NBODY_ERR_CAPACITY, "more bodies than NbodyConfig.capacity");
+    if (n > size_t(h->cfg.capacity)) return fail(h, NBODY_ERR_CAPACITY, "more bodies than NbodyConfig.capacity");
     int rc = ensure_aos(h, s, n);
     if (rc) return rc;
     const char* src = static_cast<const char*>(aos);
     for (size_t k = 0; k < n; ++k) std::memcpy(s.h_aos + 10 * k, src + k * stride, 80);
     if (n) HIP_TRY(h, hipMemcpyAsync(s.d_aos, s.h_aos, n * 80, hipMemcpyHostToDevice, h->stream));
-    launch_aos_to_soa(h->stream, s.d_aos, 10, int(n), s.d, 0);
+    const size_t G = size_t(s.d.n_seg), blk = (n + G - 1) / G;   // contiguous index blocks keep the ascending-partner order
+    for (size_t g = 0; g < G; ++g) {
+        const size_t lo = std::min(n, g * blk), hi = std::min(n, lo + blk);
+        s.count_upper[g] = int(hi - lo);
+        s.h_count[g] = int(hi - lo);
+        if (int(g) == s.d.my_seg) {
+            launch_aos_to_soa(h->stream, s.d_aos + 10 * lo, 10, int(hi - lo), s.d, 0);
+            s.n_local = hi - lo;
+            h->first_global = lo; h->n_at_upload = hi - lo;
+        } else {
+            launch_aos_to_pos(h->stream, s.d_aos + 10 * lo, 10, int(hi - lo), s.d.pos_all + g * size_t(s.d.cap));
+        }
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemsetAsync(s.d.escaped, 0, sizeof(int), h->stream));
-    s.n_local = n;
+    HIP_TRY(h, hipMemcpyAsync(s.d.seg_count, s.h_count, sizeof(int) * G, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     s.count_dirty = false;
-    return push_count(h, s);
+    return NBODY_OK;
 }
 
 int download(NbodyHandle* h, void* aos, size_t cap, size_t stride, size_t* n_out) {
@@ -383,8 +508,20 @@ int count(NbodyHandle* h, size_t* n_out) {
     return NBODY_OK;
 }
 
+int count_global(NbodyHandle* h, size_t* n_out) {   // as of the last exchange
+    State& s = *h->f64;
+    s.count_dirty = true;
+    int rc = sync_count(h, s);
+    if (rc) return rc;
+    size_t t = 0;
+    for (int c : s.count_upper) t += size_t(c);
+    *n_out = t;
+    return NBODY_OK;
+}
+
 int add_point(NbodyHandle* h, const void* particle) {   // Vec::push (brute_force.rs:92-94)
     State& s = *h->f64;
+    if (s.d.n_seg > 1) return fail(h, NBODY_ERR_INVALID, "add_point on a sharded f64 world is not supported (f32 handles: collective push / swap_remove)");
     int rc = sync_count(h, s);
     if (rc) return rc;
     if (s.n_local >= size_t(s.d.cap)) return fail(h, NBODY_ERR_CAPACITY, "capacity exhausted");
@@ -400,6 +537,7 @@ int add_point(NbodyHandle* h, const void* particle) {   // Vec::push (brute_forc
 
 int remove_point(NbodyHandle* h, size_t index) {   // Vec::swap_remove (brute_force.rs:96-98)
     State& s = *h->f64;
+    if (s.d.n_seg > 1) return fail(h, NBODY_ERR_INVALID, "remove_point on a sharded f64 world is not supported (f32 handles: collective push / swap_remove)");
     int rc = sync_count(h, s);
     if (rc) return rc;
     if (index >= s.n_local) return fail(h, NBODY_ERR_INVALID, "swap_remove index out of range");
@@ -466,6 +604,8 @@ int steps(NbodyHandle* h, int k) {
 int update_forces(NbodyHandle* h) {
     State& s = *h->f64;
     if (h->cfg.method == NBODY_BARNES_HUT && !s.bounds_set) return fail(h, NBODY_ERR_INVALID, "nbody_set_bounds has not been called");
+    int rc = exchange(h, s);
+    if (rc) return rc;
     return forces(h, s);
 }
 
@@ -500,6 +640,7 @@ int reset_stats(NbodyHandle* h) {
 
 int energy(NbodyHandle* h, double* kinetic, double* potential) {
     State& s = *h->f64;
+    if (s.d.n_seg > 1) return fail(h, NBODY_ERR_INVALID, "nbody_energy on a sharded f64 world is not supported (a rank holds the velocities of its own block only)");
     int rc = sync_count(h, s);
     if (rc) return rc;
     const size_t n = s.n_local;

@@ -10,6 +10,7 @@ int clone_state(NbodyHandle* src, NbodyHandle* dst);
 int upload(NbodyHandle* h, const void* aos, size_t n, size_t stride);
 int download(NbodyHandle* h, void* aos, size_t cap, size_t stride, size_t* n_out);
 int count(NbodyHandle* h, size_t* n_out);
+int count_global(NbodyHandle* h, size_t* n_out);
 int add_point(NbodyHandle* h, const void* particle);
 int remove_point(NbodyHandle* h, size_t index);
 int set_settings(NbodyHandle* h, double g, double g_soft, double dt, double theta2);

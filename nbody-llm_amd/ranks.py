@@ -43,12 +43,12 @@ def _package():
 
 
 def make_ics(nb, ics: dict) -> np.ndarray:
-    n, seed = int(ics["n"]), int(ics.get("seed", 20250523))
-    pts = nb.disc(n, seed=seed) if ics.get("kind", "plummer") == "disc" else nb.plummer(n, seed=seed)
+    n, seed, f64 = int(ics["n"]), int(ics.get("seed", 20250523)), bool(ics.get("f64", False))
+    pts = nb.disc(n, seed=seed, f64=f64) if ics.get("kind", "plummer") == "disc" else nb.plummer(n, seed=seed, f64=f64)
     if ics.get("mass_jitter") is not None:
-        pts["mass"] *= np.random.default_rng(int(ics["mass_jitter"])).uniform(0.5, 1.5, len(pts)).astype(np.float32)
+        pts["mass"] *= np.random.default_rng(int(ics["mass_jitter"])).uniform(0.5, 1.5, len(pts)).astype(pts["mass"].dtype)
     if ics.get("velocity_scale") is not None:
-        pts["velocity"] *= np.float32(ics["velocity_scale"])
+        pts["velocity"] *= pts["velocity"].dtype.type(ics["velocity_scale"])
     return pts
 
 
@@ -127,7 +127,7 @@ def _rank_main(cfg: dict, rank: int, failed: list) -> None:
         if cfg["sim"].get("shard", "index") == "spatial":
             arrays["ids"] = sim.download_ids()
         st = sim.stats()
-        meta = {"rank": rank, "count": int(len(pts)), "count_global": int(sim.count_global()), "wall_s": wall, "elapsed": sim.elapsed(),
+        meta = {"rank": rank, "f64": bool(sim.f64), "count": int(len(pts)), "count_global": int(sim.count_global()), "wall_s": wall, "elapsed": sim.elapsed(),
                 "transport": sim.comm_transport(), "steps": int(st.steps), "interactions": int(st.interactions),
                 "node_visits": int(st.node_visits), "tree_nodes": int(st.tree_nodes), "local_range": list(sim.local_range())}
         if cfg["sim"].get("shard", "index") == "spatial":
@@ -220,7 +220,7 @@ def run_world(cfg: dict, ranks_per_process: int = 1, timeout: float = 180.0) -> 
         z = np.load(os.path.join(out, f"rank{r}.npz"))
         with open(os.path.join(out, f"rank{r}.json")) as f:
             meta = json.load(f)
-        meta["points"] = z["points"].view(nb.PARTICLE_DTYPE)
+        meta["points"] = z["points"].view(nb.PARTICLE_DTYPE64 if meta.get("f64") else nb.PARTICLE_DTYPE)
         if "ids" in z:
             meta["ids"] = z["ids"]
         results.append(meta)

@@ -1,6 +1,7 @@
 """F = f64 across the boundary (NbodyConfig.dtype = NBODY_F64): the reference's trait is generic over Float
-(src/shared.rs:12-44) and its own driver runs f64 (src/main.rs:52-105).  One shard, strict arithmetic, host-built tree:
-bit-exact against the oracle's f64 instantiation."""
+(src/shared.rs:12-44) and its own driver runs f64 (src/main.rs:52-105).  Strict arithmetic, host-built tree: bit-exact against
+the oracle's f64 instantiation (over index-block ranks too: tests/test_multiproc_gpu.py); device-built tree and the fast
+walk: to f64 rounding."""
 import numpy as np
 import pytest
 
@@ -172,9 +173,9 @@ def test_f32_entry_points_on_an_f64_handle_and_back(gpu):
         v = C.c_float()
         sim._check(nb.lib.nbody_elapsed(sim._h, C.byref(v)))
         assert v.value == 0.5
-        with pytest.raises(nb.NbodyError) as e:
-            sim.comm_init(nb.comm_unique_id())
-        assert e.value.code == nb.NBODY_ERR_INVALID
+        sim.comm_init(nb.comm_local_id())            # (a world of one with a communicator: f64 worlds shard by index blocks)
+        sim.step()
+        assert sim.comm_transport() == "ipc" and sim.count_global() == 64
         bad = np.zeros(64, nb.PARTICLE_DTYPE)
         assert nb.lib.nbody_upload(sim._h, bad.ctypes.data, 64, 40) == nb.NBODY_ERR_INVALID      # 40-byte records on an f64 handle
     with nb.Simulation(nb.plummer(64, seed=57), *BOX, method=nb.BRUTE_FORCE) as sim:
@@ -186,9 +187,17 @@ def test_f32_entry_points_on_an_f64_handle_and_back(gpu):
         sim._check(nb.lib.nbody_step_by_f64(sim._h, 1e-3))
         sim._check(nb.lib.nbody_elapsed_f64(sim._h, C.byref(d)))
         assert d.value == float(np.float32(1e-3))
-    with pytest.raises(nb.NbodyError) as e:
-        nb.Simulation(ics, *BOX, rank=0, world_size=2, capacity=64)
+    with pytest.raises(nb.NbodyError) as e:          # f64 worlds are sharded by index blocks only
+        nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, rank=0, world_size=2, capacity=64, shard_mode=nb.SHARD_SPATIAL)
     assert e.value.code == nb.NBODY_ERR_INVALID
+    with nb.Simulation(ics, *BOX, rank=1, world_size=2, capacity=64) as half:      # the second block of two
+        assert half.f64 and half.local_range() == (32, 32) and len(half) == 32
+        with pytest.raises(nb.NbodyError) as e:
+            half.step()                                                               # no communicator
+        assert e.value.code == nb.NBODY_ERR_COMM
+        for call in (lambda: half.add_point(ics[0]), lambda: half.remove_point(0), half.energy):
+            with pytest.raises(nb.NbodyError):
+                call()
 
 
 def test_f64_tracks_f32(gpu):
@@ -264,3 +273,55 @@ def test_barnes_hut_f64_device_tree_trajectory_and_close_pairs(gpu, orc):
     assert len(ref) < 2800 and depth > 22
     assert np.abs(got["position"] - ref["position"]).max() < 1e-11
     assert np.array_equal(got["mass"], ref["mass"])
+
+
+@pytest.mark.parametrize("tree", ["host", "device"])
+@pytest.mark.parametrize("leaf", ["reference", "direct"])
+@pytest.mark.parametrize("n,theta2,split", [(1, 0.25, 0), (2, 0.25, 0), (9, 1.0, 0), (1000, 0.25, 0), (5000, 0.5, 1), (20000, 0.25, 0), (65536, 0.25, 0), (65536, 0.25, 7)])
+def test_barnes_hut_f64_fast_walk(gpu, orc, n, theta2, leaf, tree, split):
+    """NBODY_MATH_FAST on an f64 handle: one running sum per lane (FMA, 1/sqrt) over a node range split into segments, instead
+    of the reference's nested sums.  The opening tests are the reference's, so on the host-built tree the node counts equal
+    the oracle's; accelerations agree to f64 rounding -- 1e-12 of the largest, and every body to 1e-9 of its OWN |a|."""
+    nb = gpu
+    sd = dict(g=1.0, g_soft=0.01, dt=1e-3, theta2=theta2)
+    ics = nb.plummer(n, seed=58, f64=True)
+    ref = ics.copy().astype(orc.P64)
+    acc_n, vis_n = orc.bh_update_forces(ref, sd, BOX[0], BOX[1], threads=8, leaf_mode=1 if leaf == "direct" else 0)
+    with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE if tree == "device" else nb.TREE_HOST,
+                       leaf_mode=nb.LEAF_DIRECT if leaf == "direct" else nb.LEAF_REFERENCE, tuning=dict(bh_walk_split=split)) as sim:
+        assert sim.f64
+        sim.settings = nb.Settings(**sd)
+        sim.update_forces()
+        got = sim.get_points()
+        s = sim.stats()
+    if tree == "host":
+        assert (s.interactions, s.node_visits) == (acc_n, vis_n)
+    else:
+        assert abs(s.interactions - acc_n) <= max(2, 1e-6 * acc_n) and abs(s.node_visits - vis_n) <= max(2, 1e-6 * vis_n)
+    a, r = got["acceleration"], ref["acceleration"]
+    own = np.maximum(np.linalg.norm(r, axis=1), 1e-300)
+    err = np.linalg.norm(a - r, axis=1) / own
+    if tree == "host":
+        assert rel_err(a, r) < 1e-12 and err.max() < 1e-9, (rel_err(a, r), err.max())
+    else:   # a centre of mass in its last bits can flip a test that sits on its threshold (as for f32, far rarer)
+        assert np.median(err) < 1e-12 and np.count_nonzero(err > 1e-9) <= max(1, n // 20000), (np.median(err), err.max())
+
+
+def test_barnes_hut_f64_fast_trajectory_tracks_the_strict_one(gpu):
+    """20 steps in a tight box (bodies leave): the fast f64 run, device tree and host tree, stays with the bit-exact strict run."""
+    nb = gpu
+    box = ((0.0, 0.0, 0.0), 3.0)
+    st = nb.Settings(1.0, 0.05, 1e-2, 0.25)
+    ics = nb.plummer(6000, seed=59, f64=True)
+    runs = {}
+    for name, kw in (("strict", dict(math_mode=nb.STRICT)), ("fast host", dict(math_mode=nb.FAST, tree_build=nb.TREE_HOST)), ("fast", dict(math_mode=nb.FAST))):
+        with nb.Simulation(ics, *box, method=nb.BARNES_HUT, **kw) as sim:
+            sim.settings = st
+            sim.init()
+            sim.steps(20)
+            runs[name] = sim.get_points()
+    assert len(runs["strict"]) < 6000
+    for name in ("fast host", "fast"):
+        assert len(runs[name]) == len(runs["strict"])
+        assert np.array_equal(runs[name]["mass"], runs["strict"]["mass"])
+        assert np.abs(runs[name]["position"] - runs["strict"]["position"]).max() < 1e-11, name

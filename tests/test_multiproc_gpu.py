@@ -222,6 +222,46 @@ def test_trait_surface_on_spatial_ranks_push_swap_remove_clone(gpu, tmp_path):
     assert_same_up_to_flips(got["acceleration"], ref["acceleration"], 1e-5)
 
 
+@pytest.mark.parametrize("G,method,leaf", [(2, "bf", "reference"), (4, "bf", "reference"), (2, "bh", "reference"), (4, "bh", "direct")])
+def test_f64_ranks_are_bit_equal_to_one_handle_and_the_oracle(gpu, orc, tmp_path, G, method, leaf):
+    """F = f64 (the precision the reference's own driver runs, src/main.rs:52-105) over index-block shards: strict arithmetic,
+    the replicated tree built on the host; with bodies leaving a tight box the world equals the one-handle run and the
+    oracle's f64 instantiation bit for bit."""
+    nb = gpu
+    from nbody_llm_amd import ranks
+    box = [[0.0, 0.0, 0.0], 3.0]
+    sd = dict(g=1.0, g_soft=0.05, dt=1e-2, theta2=0.25)
+    cfg = world_cfg(tmp_path, G, dict(method=method, math="strict", leaf=leaf), dict(n=1500, seed=81, f64=True), sd, [["steps", 4], ["step_by", -5e-3], ["update_forces"]], box=box)
+    res = launch(cfg, G)
+    got = ranks.gather_world(res)
+    assert got.dtype == nb.PARTICLE_DTYPE64 and all(r["f64"] for r in res)
+    ref = ranks.make_ics(nb, cfg["ics"]).astype(orc.P64)
+    lm = 1 if leaf == "direct" else 0
+    for dt in (1e-2, 1e-2, 1e-2, 1e-2, -5e-3):
+        ref = orc.bf_step_by(ref, sd, box[0], box[1], dt) if method == "bf" else orc.bh_step_by(ref, sd, box[0], box[1], dt, threads=4, leaf_mode=lm)[0]
+    if method == "bf":
+        orc.bf_update_forces(ref, sd)
+    else:
+        orc.bh_update_forces(ref, sd, box[0], box[1], threads=4, leaf_mode=lm)
+    assert len(got) == len(ref) < 1500 and sum(r["count"] for r in res) == res[0]["count_global"] == len(ref)
+    for f in FIELDS:
+        assert np.array_equal(got[f].view(np.uint64), ref[f].view(np.uint64)), f
+
+
+def test_f64_fast_walk_ranks(gpu, tmp_path):
+    """NBODY_MATH_FAST on f64 ranks: the fast walk over the replicated host-built tree, to f64 rounding of the one-handle run."""
+    nb = gpu
+    from nbody_llm_amd import ranks
+    sd = dict(g=1.0, g_soft=0.01, dt=5e-3, theta2=0.25)
+    cfg = world_cfg(tmp_path, 3, dict(method="bh", math="fast", tree="host"), dict(n=6000, seed=82, f64=True), sd, [["steps", 5]], box=[[0.0, 0.0, 0.0], 4.0])
+    res = launch(cfg, 3)
+    got = ranks.gather_world(res)
+    ref, s1 = single(nb, cfg)
+    assert len(got) == len(ref) < 6000
+    assert np.abs(got["position"] - ref["position"]).max() < 1e-12
+    assert sum(r["interactions"] for r in res) == s1.interactions
+
+
 def test_ranks_created_unlike_fail_at_comm_init_instead_of_hanging(gpu, tmp_path):
     """Two ranks that disagree on the exchange scheme (NBODY_CROSS_SYM) would deadlock in the send/recv round of partial
     sums; nbody_comm_init compares what every rank was created with and refuses."""
