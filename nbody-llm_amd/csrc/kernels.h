@@ -14,8 +14,9 @@ struct Tuning {
     int cross_sym = 1;          // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided  [NBODY_CROSS_SYM]
     int sym_packed = 1;         // 1: packed-fp32 pair evaluation (pair_evals_pk), 0: scalar                                       [NBODY_SYM_PACKED]
     int bf_fast_variant = 0;    // 0: symmetric kernels where they apply, 1..: the LDS-tiled one-sided forms (kernels_bf.hip)       [NBODY_BF_VARIANT]
-    int sym_wpb = 12;           // k_bf_sym: waves per workgroup: 16, 12 or 8                                                       [NBODY_SYM_WPB]
+    int sym_wpb = 4;            // k_bf_sym: waves per workgroup: 4 (default), 8, 12 or 16                                           [NBODY_SYM_WPB]
     int sym_rounds = 1;         // k_bf_sym: rounds of workgroups per CU
+    int sym_k = 0;              // k_bf_sym: waves (slices) per resident set; 0 = by the plan's rule
     int sym_reduce_split = 1;   // plane reduction: 1 = several waves per 64 bodies, 0 = one thread per body
     int cross_slots = 3072;     // k_bf_cross: waves the chunk visits are dealt to
     int cross_ipt = 0;          // k_bf_cross: resident bodies per lane: 0 = by rule, 4, 8

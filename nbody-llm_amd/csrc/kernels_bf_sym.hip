@@ -460,27 +460,36 @@ SymPlan make_sym_plan(int n_upper) {
     p.A = (n_upper + 64 * IPT - 1) / (64 * IPT);
     p.sym_sets = (p.A + 1) / 2 - 1;             // ceil(A/2) - 1 sets are met symmetrically
     const int L = IPT * p.sym_sets;              // chunk visits per set, all of equal cost
-    // waves per set: every workgroup is CU-sized (wpb waves; the register budget admits 4 waves per
-    // SIMD), so the grid is dealt evenly; `rounds` > 1 makes shorter waves in several rounds, which
-    // trims the tail at the price of more resident-side planes
-    p.wpb = tuning().sym_wpb == 8 ? 8 : tuning().sym_wpb == 12 ? 12 : 16;
-    if (n_upper <= 8192 && tuning().sym_wpb == 12) p.wpb = 8;   // a small shard (8 GPUs at N = 65 536): one-chunk waves, smaller workgroups deal better (-9 us)
-    const int resident_wgs_per_cu = (p.wpb == 8) ? 2 : 1;
-    const int slots = 256 * resident_wgs_per_cu * p.wpb;  // waves the chip holds at once
-    // A * K waves run in ceil(A*K/slots) rounds; pick the K (few, long slices preferred) whose last
-    // round is fullest -- e.g. A = 2048 sets: K = 1 would fill 2/3 of one round, K = 3 fills two
+    // Workgroups of 4 waves (one per SIMD; the register budget admits three per CU) unless tuned otherwise.  Round 2 used
+    // CU-sized workgroups of 12: at mid sizes their grid is smaller than the chip (N = 16 384: 160 workgroups on 256 CUs,
+    // 62 % of the rate the kernel reaches at N = 65 536) and even at N = 65 536 three small workgroups per CU finish 2.8 %
+    // earlier (profiles/r03_sym_plan_sweep.txt: K and workgroup size swept at 12 sizes).
+    const int want = tuning().sym_wpb;
+    p.wpb = want == 8 ? 8 : want == 12 ? 12 : want == 16 ? 16 : 4;
     int K = 1;
-    double best = 0.0;
-    const int k_hi = std::min(126, std::min(L, std::max(1, slots * std::max(1, tuning().sym_rounds) * 4 / p.A)));
-    for (int k = 1; k <= k_hi; ++k) {
-        const long long waves = (long long)p.A * k;
-        const long long rounds = (waves + slots - 1) / slots;
-        if (rounds > 4 * std::max(1, tuning().sym_rounds) && k > 1) break;
-        const double fill = double(waves) / double(rounds * slots);
-        const double even = (L % k == 0) ? 1.0 : double(L / k) / double(L / k + 1);  // shortest/longest slice
-        const double per_wave = double(L) / k / (double(L) / k + 0.3);  // set-up cost of a wave ~ 0.3 chunk
-        if (fill * even * per_wave > best + 1e-9) { best = fill * even * per_wave; K = k; }
+    if (p.wpb == 4) {
+        // waves per set, from that sweep: one-chunk slices while the set's chunk sequence is short (every wave then has the
+        // same work and there are at most ~2 waves per SIMD), two-chunk slices up to L = 160, beyond that 64 slices per set
+        // (a multiple of the workgroup size, so the resident-side sums of a workgroup leave as one plane)
+        K = L <= 100 ? L : L <= 160 ? (L + 1) / 2 : 64;
+    } else {
+        const int resident_wgs_per_cu = (p.wpb == 8) ? 2 : 1;
+        const int slots = 256 * resident_wgs_per_cu * p.wpb;  // waves the chip holds at once
+        // A * K waves run in ceil(A*K/slots) rounds; pick the K (few, long slices preferred) whose last
+        // round is fullest -- e.g. A = 2048 sets: K = 1 would fill 2/3 of one round, K = 3 fills two
+        double best = 0.0;
+        const int k_hi = std::min(126, std::min(L, std::max(1, slots * std::max(1, tuning().sym_rounds) * 4 / p.A)));
+        for (int k = 1; k <= k_hi; ++k) {
+            const long long waves = (long long)p.A * k;
+            const long long rounds = (waves + slots - 1) / slots;
+            if (rounds > 4 * std::max(1, tuning().sym_rounds) && k > 1) break;
+            const double fill = double(waves) / double(rounds * slots);
+            const double even = (L % k == 0) ? 1.0 : double(L / k) / double(L / k + 1);  // shortest/longest slice
+            const double per_wave = double(L) / k / (double(L) / k + 0.3);  // set-up cost of a wave ~ 0.3 chunk
+            if (fill * even * per_wave > best + 1e-9) { best = fill * even * per_wave; K = k; }
+        }
     }
+    if (tuning().sym_k > 0) K = std::min(126, tuning().sym_k);   // (the cut points live in a 128-entry device array)
     if (K > L) K = L;
     if (K < 1) K = 1;
     p.K = K;
@@ -526,22 +535,22 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
         constexpr bool PKV = true;
         if (dbg == 4) {
 #ifdef NBODY_TUNING
-            if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4);
+            if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else if (p.wpb == 4) SYM_LAUNCH(4, 4); else SYM_LAUNCH(16, 4);
 #endif
         } else {
-            if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
+            if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else if (p.wpb == 4) SYM_LAUNCH(4, 0); else SYM_LAUNCH(16, 0);
         }
     } else {
         constexpr bool PKV = false;
         if (dbg >= 4 && dbg <= 7) {
 #ifdef NBODY_TUNING
-            if (dbg == 4) { if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else SYM_LAUNCH(16, 4); }
+            if (dbg == 4) { if (p.wpb == 12) SYM_LAUNCH(12, 4); else if (p.wpb == 8) SYM_LAUNCH(8, 4); else if (p.wpb == 4) SYM_LAUNCH(4, 4); else SYM_LAUNCH(16, 4); }
             else if (dbg == 5) SYM_LAUNCH(16, 5);
             else if (dbg == 6) SYM_LAUNCH(16, 6);
             else SYM_LAUNCH(16, 7);
 #endif
         } else {
-            if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else SYM_LAUNCH(16, 0);
+            if (p.wpb == 12) SYM_LAUNCH(12, 0); else if (p.wpb == 8) SYM_LAUNCH(8, 0); else if (p.wpb == 4) SYM_LAUNCH(4, 0); else SYM_LAUNCH(16, 0);
         }
     }
 #undef SYM_LAUNCH

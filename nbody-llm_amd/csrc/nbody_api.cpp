@@ -254,7 +254,7 @@ constexpr size_t kShardedSymMinBodies = 2048; // sharded: own-own symmetric + re
 // (re)build the symmetric kernel's plan when the number of resident sets changes
 int ensure_sym_plan(NbodyHandle* h) {
     const int A = int((std::max<size_t>(1, h->n_local) + 511) / 512);  // (an empty shard still plans one set)
-    const int knobs = nbody::tuning().sym_wpb * 100 + nbody::tuning().sym_rounds;
+    const int knobs = nbody::tuning().sym_wpb * 100 + nbody::tuning().sym_rounds + nbody::tuning().sym_k * 10000;
     if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == knobs) return NBODY_OK;
     h->sym_waves = knobs;
     h->sym_plan = nbody::make_sym_plan(int(std::max<size_t>(1, h->n_local)));
@@ -1785,7 +1785,7 @@ struct Knob { const char* name; int nbody::Tuning::*field; bool tuning_build_onl
 const Knob kKnobs[] = {
     {"cross_sym", &nbody::Tuning::cross_sym, false}, {"sym_packed", &nbody::Tuning::sym_packed, false},
     {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false},
-    {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
+    {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_k", &nbody::Tuning::sym_k, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
     {"cross_slots", &nbody::Tuning::cross_slots, false}, {"cross_ipt", &nbody::Tuning::cross_ipt, false},
     {"cross_wpb", &nbody::Tuning::cross_wpb, false}, {"bh_walk_split", &nbody::Tuning::bh_walk_split, false},
     {"bh_walk_order", &nbody::Tuning::bh_walk_order, false}, {"bh_reduce_split", &nbody::Tuning::bh_reduce_split, false},
