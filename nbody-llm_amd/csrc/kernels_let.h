@@ -8,7 +8,7 @@ namespace let {
 constexpr int kLevels = 21;     // levels of the device build's keys
 constexpr int kMaxRanks = 16;
 
-enum { kFlagDeep = 1, kFlagNodeCapLocal = 2, kFlagCapacity = 8, kFlagNodeCap = 16,
+enum { kFlagDeep = 1, kFlagNodeCapLocal = 2, kFlagBigGroup = 4 /* kernels_tree.hip: > 4096 bodies share 16 levels */, kFlagCapacity = 8, kFlagNodeCap = 16,
        kFlagMigSpill = 32 };   // more migrants between some pair of ranks than the size its message was posted with (the
                                // step's migrant round is then made again with the exact sizes: nbody_let.cpp)
 

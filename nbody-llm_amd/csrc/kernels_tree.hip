@@ -30,6 +30,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/block/block_radix_sort.hpp>
 
 // test hook: the largest group of equal 63-bit keys the device build orders itself (1: any collision is "too deep", which
 // exercises the callers' fallback paths the way every collision did before the second keys existed)
@@ -107,32 +108,23 @@ __device__ __forceinline__ int common_levels2(const unsigned long long* __restri
 // a quarter of the histogram less, 12-16 us of a ~100 us build); what it leaves is finished here.  The first body of every
 // group of equal TOP bits (bodies that share 16 levels: a handful here and there) sorts the group by the full key
 // (insertion sort; the radix sort is stable, so equal keys keep ascending ids), and inside it every run of equal FULL
-// keys gets its second keys (levels 21..41) and is put in their order.  Groups are pairs in practice; a group of more
-// than kMaxLowGroup bodies, or a run of more than tuning().tree_max_tie (64) equal keys, is reported as too deep rather than
-// sorted by a single thread.
+// keys gets its second keys (levels 21..41) and is put in their order.  Groups are pairs in practice.  A group of more
+// than kMaxLowGroup bodies (a dense clump inside one level-16 cell, 1e-3 of a width-64 box) is not sorted by one thread:
+// its bounds go on a list and k_tree_big_groups sorts it with a workgroup (up to kMaxBigGroup bodies, kMaxBigGroups
+// groups per build).  Beyond that -- and for a run of more than tuning().tree_max_tie (64) equal FULL keys -- the build
+// raises a flag: 1 = "deeper than the build's 42 levels", 4 = "a clump larger than the build sorts" (the single-GPU step
+// then builds on the host; a spatial rank reports it as what it is).
 constexpr int kSortLowBits = 15;    // key bits the radix sort leaves to k_tree_ties (levels 16..20)
 constexpr int kMaxLowGroup = 256;
+constexpr int kBigItems = 16;
+constexpr int kMaxBigGroup = 256 * kBigItems;   // 4096 bodies: one workgroup's block_radix_sort
+constexpr int kMaxBigGroups = 255;              // list entries {begin, end} behind the counter
+
+// runs of equal FULL keys inside the sorted group [a0, e): second keys (levels 21..41), put in their order
 template <class P4, class Real>
-__global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, const int* __restrict__ count, Real cx0, Real cy0,
-                                                   Real cz0, Real width, unsigned long long* __restrict__ keys,
-                                                   unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
-                                                   int kMaxTie) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int n = *count;
-    if (j + 1 >= n) return;
-    const unsigned long long top = keys[j] >> kSortLowBits;
-    if ((keys[j + 1] >> kSortLowBits) != top || (j > 0 && (keys[j - 1] >> kSortLowBits) == top)) return;
-    int e = j + 2;
-    while (e < n && e - j <= kMaxLowGroup && (keys[e] >> kSortLowBits) == top) ++e;
-    if (e - j > kMaxLowGroup) { atomicOr(flags, 1); return; }
-    for (int q = j + 1; q < e; ++q) {           // by the full key
-        const unsigned long long k = keys[q];
-        const int id = ids[q];
-        int r = q - 1;
-        while (r >= j && keys[r] > k) { keys[r + 1] = keys[r]; ids[r + 1] = ids[r]; --r; }
-        keys[r + 1] = k; ids[r + 1] = id;
-    }
-    for (int a = j; a + 1 < e;) {               // runs of equal full keys: by the second key
+__device__ void finish_equal_key_runs(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width, unsigned long long* __restrict__ keys,
+                                      unsigned long long* __restrict__ keys2, int* __restrict__ ids, int a0, int e, int* __restrict__ flags, int kMaxTie) {
+    for (int a = a0; a + 1 < e;) {
         int z = a + 1;
         while (z < e && keys[z] == keys[a]) ++z;
         if (z - a > 1) {
@@ -147,6 +139,68 @@ __global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, c
             }
         }
         a = z;
+    }
+}
+
+template <class P4, class Real>
+__global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, const int* __restrict__ count, Real cx0, Real cy0,
+                                                   Real cz0, Real width, unsigned long long* __restrict__ keys,
+                                                   unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
+                                                   int kMaxTie, int* __restrict__ big_list /* [0] = count, then {begin, end} pairs */) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int n = *count;
+    if (j + 1 >= n) return;
+    const unsigned long long top = keys[j] >> kSortLowBits;
+    if ((keys[j + 1] >> kSortLowBits) != top || (j > 0 && (keys[j - 1] >> kSortLowBits) == top)) return;
+    int e = j + 2;
+    while (e < n && e - j <= kMaxBigGroup && (keys[e] >> kSortLowBits) == top) ++e;
+    if (e - j > kMaxLowGroup) {
+        if (e - j > kMaxBigGroup) { atomicOr(flags, 4); return; }
+        const int slot = atomicAdd(big_list, 1);
+        if (slot >= kMaxBigGroups) { atomicOr(flags, 4); return; }
+        big_list[1 + 2 * slot] = j;
+        big_list[2 + 2 * slot] = e;
+        return;
+    }
+    for (int q = j + 1; q < e; ++q) {           // by the full key
+        const unsigned long long k = keys[q];
+        const int id = ids[q];
+        int r = q - 1;
+        while (r >= j && keys[r] > k) { keys[r + 1] = keys[r]; ids[r + 1] = ids[r]; --r; }
+        keys[r + 1] = k; ids[r + 1] = id;
+    }
+    finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, j, e, flags, kMaxTie);
+}
+
+// the listed groups (257 .. 4096 bodies sharing 16 levels), one workgroup each: a stable block radix sort on the 15 low
+// key bits (the group's top bits are equal), then the runs of equal full keys as above
+template <class P4, class Real>
+__global__ __launch_bounds__(256) void k_tree_big_groups(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width,
+                                                         unsigned long long* __restrict__ keys, unsigned long long* __restrict__ keys2,
+                                                         int* __restrict__ ids, int* __restrict__ flags, int kMaxTie, const int* __restrict__ big_list) {
+    using Sort = rocprim::block_radix_sort<unsigned long long, 256, kBigItems, int>;
+    __shared__ typename Sort::storage_type storage;
+    const int n_groups = min(big_list[0], kMaxBigGroups);
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int b = big_list[1 + 2 * g], e = big_list[2 + 2 * g];
+        unsigned long long k[kBigItems];
+        int v[kBigItems];
+#pragma unroll
+        for (int i = 0; i < kBigItems; ++i) {
+            const int q = b + int(threadIdx.x) * kBigItems + i;
+            k[i] = q < e ? keys[q] : ~0ull;     // (the padding sorts behind everything: the sort is stable and it comes last)
+            v[i] = q < e ? ids[q] : -1;
+        }
+        __syncthreads();
+        Sort().sort(k, v, storage, 0, kSortLowBits);
+#pragma unroll
+        for (int i = 0; i < kBigItems; ++i) {
+            const int q = b + int(threadIdx.x) * kBigItems + i;
+            if (q < e) { keys[q] = k[i]; ids[q] = v[i]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, b, e, flags, kMaxTie);
+        __syncthreads();
     }
 }
 
@@ -456,7 +510,8 @@ size_t scratch_bytes(size_t n_cap) {
     unsigned long long* k = nullptr; int* v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, n_cap, 0, 64, 0);
     (void)rocprim::exclusive_scan(nullptr, scan_i, v, v, 0, n_cap, rocprim::plus<int>(), 0);
-    return (std::max(sort_bytes, std::max(scan_i, sum4_scan_tmp_bytes(n_cap))) + 255) / 256 * 256;
+    // (at least 4 KB: k_tree_ties keeps its list of big groups there between the sort and the scans)
+    return (std::max<size_t>(4096, std::max(sort_bytes, std::max(scan_i, sum4_scan_tmp_bytes(n_cap)))) + 255) / 256 * 256;
 }
 
 // ---- sharded runs: the tree is built over the live bodies of ALL segments (every GPU builds the
@@ -547,8 +602,12 @@ int sort_keys_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, c
     // (bits [15, 63): the unused tail's keys are all ones and stay behind every real body -- the sort is stable and the
     // tail comes last in the input; k_tree_ties finishes the low bits)
     if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), kSortLowBits, 63, s) != hipSuccess) return -1;
+    int* big_list = static_cast<int*>(L.tmp);   // (the sort is done with its scratch; the scans take it over after this)
+    (void)hipMemsetAsync(big_list, 0, sizeof(int), s);
     hipLaunchKernelGGL((k_tree_ties<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width,
-                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie));
+                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie), big_list);
+    hipLaunchKernelGGL((k_tree_big_groups<P4, Real>), dim3(16), dim3(256), 0, s, pos, center[0], center[1], center[2], width, L.keys, L.keys2, L.ids,
+                       out_info + 1, std::max(1, tuning().tree_max_tie), big_list);
     return 0;
 }
 template <class P4>

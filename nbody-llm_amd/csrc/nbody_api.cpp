@@ -689,7 +689,7 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
     for (int s = 0; s < sh.n_seg; ++s) h->seg_count_host[s] = h->h_counts[s];
     h->n_local = size_t(h->h_counts[sh.my_seg]);
     h->count_dirty = false;
-    if (h->h_tree_info[1] & 1) { *fell_back = true; return NBODY_OK; }
+    if (h->h_tree_info[1] & 5) { *fell_back = true; return NBODY_OK; }   // deeper than 42 levels / a clump beyond the build's sort: host build
     const int n_nodes = h->h_tree_info[0];
     const size_t n_order = h->n_local;             // bodies this GPU walks
     const size_t n_tree = total_upper(h);          // bodies in the tree (now exact)

@@ -245,7 +245,7 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
             return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
         HIP_TRY(h, hipMemcpyAsync(s.h_tree_info, s.d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (s.h_tree_info[1] & 1) { *fell_back = true; return NBODY_OK; }
+        if (s.h_tree_info[1] & 5) { *fell_back = true; return NBODY_OK; }
         if (!(s.h_tree_info[1] & 2)) break;
         s.dev_nodes = size_t(s.h_tree_info[0]);   // the array was too small: the build says how many it needs
         s.node_cap = 0;

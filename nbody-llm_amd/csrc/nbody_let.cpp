@@ -454,7 +454,10 @@ int check_flags(NbodyHandle* h) {
             for (int q = 0; q < s.G; ++q) if (rb[q].flags) who += " rank " + std::to_string(q) + ": build flags " + std::to_string(rb[q].flags) + ";";
         who += " flag word " + std::to_string(f);
     }
+    // (an unsorted clump also looks "too deep" to the passes behind the sort: the clump is the cause)
+    if (f & kFlagBigGroup) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: more than 4096 bodies of one rank share 16 levels of the tree: beyond what the device build sorts;" + who);
     if (f & (kFlagDeep)) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 42 levels (coincident?);" + who);
+    if (f & kFlagBigGroup) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: more than 4096 bodies of one rank share 16 levels of the tree (a clump inside a cell 1.5e-5 of the box wide): beyond what the device build sorts, and a spatial rank has no host build to hand the step to" + who);
     if (f & kFlagCapacity) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: a rank's capacity is exhausted by immigrants");
     if (f & (kFlagNodeCap | kFlagNodeCapLocal)) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: node array too small");
     return fail(h, NBODY_ERR_INVALID, "spatial shards: the device raised flag " + std::to_string(f));
@@ -736,6 +739,7 @@ size_t exchange_layout(const int* m, int G, int me, long long clamp, bool packed
 static int flags_to_error(NbodyHandle* h, State& s, int f) {
     if (!f) return NBODY_OK;
     const std::string who = " (flag word " + std::to_string(f) + ")";
+    if (f & kFlagBigGroup) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: more than 4096 bodies of one rank share 16 levels of the tree (a clump inside a cell 1.5e-5 of the box wide): beyond what the device build sorts, and a spatial rank has no host build to hand the step to" + who);
     if (f & kFlagDeep) return fail(h, NBODY_ERR_TREE_DEPTH, "spatial shards: two bodies separate only below the device build's 42 levels (coincident?)" + who);
     if (f & kFlagCapacity) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: a rank's capacity is exhausted by immigrants");
     if (f & (kFlagNodeCap | kFlagNodeCapLocal)) return fail(h, NBODY_ERR_CAPACITY, "spatial shards: node array too small");

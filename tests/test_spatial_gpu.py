@@ -351,3 +351,32 @@ def test_randomised_worlds_against_the_single_gpu_run():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all OK" in r.stdout
+
+
+def test_spatial_ranks_with_a_clump_inside_one_level_16_cell(gpu):
+    """More than 256 bodies that share 16 levels of the tree (kernels_tree.hip sorts such a group with a workgroup): the spatial
+    world still equals the one-handle device-tree run; beyond 4096 the rank that holds the clump says what it is."""
+    nb = gpu
+    st = nb.Settings(1.0, 1e-3, 1e-3, 0.25)
+    rng = np.random.default_rng(7)
+    for clump, ok in ((1500, True), (9000, False)):   # (9000: whatever the cut, one of the three ranks holds more than 4096 of them)
+        ics = nb.plummer(6000 + clump, seed=92)
+        w16 = np.float64(BOX[1]) / 65536.0
+        ics["position"][6000:] = (-32.0 + 36000 * w16 + w16 * (0.1 + 0.5 * rng.random((clump, 3)))).astype(np.float32)
+        ics["velocity"][6000:] = 0.0
+        sims = make_world(nb, ics, 3, BOX, st)
+        if ok:
+            nb.spatial_step(sims, forces_only=True)
+            rec, idx = nb.spatial_gather(sims, len(ics))
+            with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE) as one:
+                one.settings = st
+                one.update_forces()
+                ref = one.get_points()
+                s1 = one.stats()
+            assert all(s.stats().tree_nodes == s1.tree_nodes for s in sims)
+            assert np.abs(rec["acceleration"].astype(np.float64) - ref["acceleration"]).max() < 1e-3 * np.abs(ref["acceleration"]).max()
+        else:
+            with pytest.raises(nb.NbodyError) as e:
+                nb.spatial_step(sims, forces_only=True)
+            assert e.value.code == nb.NBODY_ERR_TREE_DEPTH and "4096 bodies" in str(e.value)
+        close(sims)
