@@ -17,6 +17,7 @@ struct Tuning {
     int sym_wpb = 4;            // k_bf_sym: waves per workgroup: 4 (default), 8, 12 or 16                                           [NBODY_SYM_WPB]
     int sym_rounds = 1;         // k_bf_sym: rounds of workgroups per CU
     int sym_k = 0;              // k_bf_sym: waves (slices) per resident set; 0 = by the plan's rule
+    int sym_min_bodies = 1024;  // single shard: below this the LDS-tiled one-sided kernel runs instead of k_bf_sym (measured: 18 against 26 us at 1 024 bodies, 28 against 43 at 4 096)
     int sym_reduce_split = 1;   // plane reduction: 1 = several waves per 64 bodies, 0 = one thread per body
     int cross_slots = 3072;     // k_bf_cross: waves the chunk visits are dealt to
     int cross_ipt = 0;          // k_bf_cross: resident bodies per lane: 0 = by rule, 4, 8

@@ -248,7 +248,6 @@ int drain_events(NbodyHandle* h) {
     return NBODY_OK;
 }
 
-constexpr size_t kSymMinBodies = 8192;       // single shard: below this the LDS-tiled one-sided kernel is used
 constexpr size_t kShardedSymMinBodies = 2048; // sharded: own-own symmetric + remote one-sided from this size up
 
 // (re)build the symmetric kernel's plan when the number of resident sets changes
@@ -322,7 +321,7 @@ int bf_forces(NbodyHandle* h) {
     // Sharded: decided from the shard CAPACITY, which every rank shares.  The live counts differ from rank
     // to rank (ragged last block, bodies leaving the box), and a rank that chose another scheme than its
     // peers would neither send nor expect the partial sums the others exchange with it (a hang in RCCL).
-    const bool sym = fast && (sharded ? size_t(h->sh.seg_cap) >= kShardedSymMinBodies : h->n_local >= kSymMinBodies);
+    const bool sym = fast && (sharded ? size_t(h->sh.seg_cap) >= kShardedSymMinBodies : h->n_local >= size_t(std::max(1024, nbody::tuning().sym_min_bodies)));
     const size_t tot = total_upper(h);
     if (sym) {
         int rc = ensure_sym_plan(h);
@@ -1785,7 +1784,8 @@ struct Knob { const char* name; int nbody::Tuning::*field; bool tuning_build_onl
 const Knob kKnobs[] = {
     {"cross_sym", &nbody::Tuning::cross_sym, false}, {"sym_packed", &nbody::Tuning::sym_packed, false},
     {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false},
-    {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_k", &nbody::Tuning::sym_k, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
+    {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_k", &nbody::Tuning::sym_k, false},
+    {"sym_min_bodies", &nbody::Tuning::sym_min_bodies, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
     {"cross_slots", &nbody::Tuning::cross_slots, false}, {"cross_ipt", &nbody::Tuning::cross_ipt, false},
     {"cross_wpb", &nbody::Tuning::cross_wpb, false}, {"bh_walk_split", &nbody::Tuning::bh_walk_split, false},
     {"bh_walk_order", &nbody::Tuning::bh_walk_order, false}, {"bh_reduce_split", &nbody::Tuning::bh_reduce_split, false},

@@ -80,7 +80,7 @@ struct NbodyHandle {
     unsigned long long* d_counters = nullptr;  // [NBODY_WALK_COUNTER_SLOTS][2] accepted, visited (summed on read)
     unsigned long long* h_counters = nullptr;  // pinned
 
-    // symmetric all-pairs kernel (fast math, single shard, n >= kSymMinBodies)
+    // symmetric all-pairs kernel (fast math; single shard: n >= Tuning::sym_min_bodies)
     nbody::SymPlan sym_plan;
     int* d_sym_bounds = nullptr;
     float4* d_planes = nullptr;

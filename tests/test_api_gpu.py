@@ -82,7 +82,13 @@ def test_statistics_and_profiling(gpu):
         sim.steps(4)
         s = sim.stats()
         assert (s.steps, s.force_launches) == (4, 4) and s.force_kernel_ms > 0
-        assert s.force_kernel_interactions == 4 * n * (n - 1)
+        # the timed launch is the symmetric kernel's rotation: every pair of two DIFFERENT resident sets met symmetrically (6 of
+        # the 8 sets' 8 partners at this size; the own-set and opposite-set pairs are the companion blocks' share)
+        assert 0.7 * 4 * n * (n - 1) <= s.force_kernel_interactions <= 4 * n * (n - 1)
+    with nb.Simulation(nb.plummer(n), *BOX, math_mode=nb.FAST, tuning=dict(sym_min_bodies=1 << 30)) as sim:   # the LDS-tiled kernel: one launch, all pairs
+        sim.set_profiling(True)
+        sim.steps(2)
+        assert sim.stats().force_kernel_interactions == 2 * n * (n - 1)
         sim.reset_stats()
         assert sim.stats().steps == 0
 
