@@ -5,7 +5,9 @@
 //     Elapsed: <duration>
 //     Performance: <x> steps/second
 // (main.rs:124-128).  Extra flags select what the reference needs a source edit for; --dtype f64 runs the
-// reference's own precision (PointParticle<f64,3>, main.rs:52-105) on the strict f64 path.
+// reference's own precision (PointParticle<f64,3>, main.rs:52-105); --integrator host steps through the trait's generic
+// `Integrator` parameter (shared.rs:99-104) with a leapfrog on the host instead of the device's fused one; --dump FILE
+// writes the final PointParticle records.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -21,13 +23,13 @@ static void usage() {
                  "usage: nbody_cli [-t threads] [-n points] [--method bh|bf] [--ic disc|plummer] [--steps K]\n"
                  "                 [--math fast|strict] [--tree auto|host|device] [--leaf reference|direct]\n"
                  "                 [--dtype f32|f64] [--dt x] [--g-soft x] [--theta2 x]\n"
-                 "                 [--width w] [--seed s]\n");
+                 "                 [--width w] [--seed s] [--integrator device|host] [--dump file]\n");
 }
 
 template <class F>
 static int run(const std::string& method, const std::string& ic, const std::string& math, const std::string& tree,
                const std::string& leaf, size_t threads, size_t num_points, size_t steps, double dt, double g_soft, double theta2,
-               double width, unsigned long long seed) {
+               double width, unsigned long long seed, const std::string& integrator, const std::string& dump) {
     using P = nbody::PointParticleT<F>;
     const bool wide = sizeof(F) == 8;
     std::vector<P> points;
@@ -52,13 +54,25 @@ static int run(const std::string& method, const std::string& ic, const std::stri
         std::printf("Running simulation without rendering...\n");  // main.rs:111
         sim->init();
         auto start = std::chrono::steady_clock::now();
-        for (size_t i = 0; i < steps; ++i) sim->step();
+        if (integrator == "host") {   // the trait's generic Integrator, on the host (simulation.hpp step_by_with)
+            nbody::LeapFrogIntegratorT<F> leapfrog;
+            leapfrog.init();
+            for (size_t i = 0; i < steps; ++i) sim->step_by_with(leapfrog, F(dt));
+        } else {
+            for (size_t i = 0; i < steps; ++i) sim->step();
+        }
         sim->sync();
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
         std::printf("Elapsed: %.6fs\n", secs);
         std::printf("Performance: %.2f steps/second\n", double(steps) / secs);
         NbodyStats st = sim->stats();
         std::printf("Bodies left: %zu  interactions/second: %.4e\n", sim->get_points().size(), double(st.interactions) / secs);
+        if (!dump.empty()) {
+            std::FILE* f = std::fopen(dump.c_str(), "wb");
+            if (!f) { std::fprintf(stderr, "cannot write %s\n", dump.c_str()); return 1; }
+            std::fwrite(sim->get_points().data(), sizeof(P), sim->get_points().size(), f);
+            std::fclose(f);
+        }
     } catch (const nbody::Error& e) {
         std::fprintf(stderr, "nbody error %d: %s\n", e.code, e.what());
         return 1;
@@ -68,7 +82,7 @@ static int run(const std::string& method, const std::string& ic, const std::stri
 
 int main(int argc, char** argv) {
     size_t threads = 0, num_points = 10000, steps = 1000;  // main.rs:33-38, :116
-    std::string method = "bh", ic = "disc", math = "fast", tree = "auto", leaf = "reference", dtype = "f32";
+    std::string method = "bh", ic = "disc", math = "fast", tree = "auto", leaf = "reference", dtype = "f32", integrator = "device", dump;
     double dt = 3e-2, g_soft = 0.02, theta2 = 1.0, width = 10.0;  // main.rs:59,103-105
     unsigned long long seed = 20250523ull;
     bool width_set = false;
@@ -88,9 +102,11 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--theta2")) theta2 = std::strtod(next(), nullptr);
         else if (!std::strcmp(argv[i], "--width")) { width = std::strtod(next(), nullptr); width_set = true; }
         else if (!std::strcmp(argv[i], "--seed")) seed = std::strtoull(next(), nullptr, 10);
+        else if (!std::strcmp(argv[i], "--integrator")) integrator = next();
+        else if (!std::strcmp(argv[i], "--dump")) dump = next();
         else { usage(); return 2; }
     }
     if (ic == "plummer" && !width_set) width = 64.0;
-    if (dtype == "f64") return run<double>(method, ic, math, tree, leaf, threads, num_points, steps, dt, g_soft, theta2, width, seed);
-    return run<float>(method, ic, math, tree, leaf, threads, num_points, steps, dt, g_soft, theta2, width, seed);
+    if (dtype == "f64") return run<double>(method, ic, math, tree, leaf, threads, num_points, steps, dt, g_soft, theta2, width, seed, integrator, dump);
+    return run<float>(method, ic, math, tree, leaf, threads, num_points, steps, dt, g_soft, theta2, width, seed, integrator, dump);
 }

@@ -8,6 +8,7 @@
 //   nbody::SimulationSettings     = shared.rs:61-78
 //   nbody::Bounds                 = shared.rs:216-243 (center, width)
 //   nbody::Simulation             = shared.rs:80-97   (abstract)
+//   nbody::IntegratorT            = shared.rs:99-104  (the trait's `I`; LeapFrogIntegratorT = shared.rs:106-149)
 //   nbody::BruteForceSimulation   = manual/brute_force.rs:11-103
 //   nbody::BarnesHutSimulation    = manual/barnes_hut.rs:93-285
 //
@@ -73,6 +74,35 @@ inline int elapsed(const NbodyHandle* h, double* t) { return nbody_elapsed_f64(h
 template <class F> constexpr int dtype_of() { return sizeof(F) == 8 ? NBODY_F64 : NBODY_F32; }
 }  // namespace abi
 
+// The reference's `Integrator<F, D, P>` (shared.rs:99-104): the trait is generic over it.  The device integrates with the
+// reference's LeapFrogIntegrator itself (kernels K1 / K3: the only integrator the reference ships, and the fast path).
+// Any other integrator runs on the host through SimulationT::step_by_with: the unfused form of step_by -- the device does
+// update_forces, the host does integrate_pre_force / retain / integrate_after_force on the synced vector.
+template <class F>
+struct IntegratorT {
+    virtual ~IntegratorT() = default;
+    virtual void init() {}
+    virtual void integrate_pre_force(std::vector<PointParticleT<F>>& points, F dt) = 0;
+    virtual void integrate_after_force(std::vector<PointParticleT<F>>& points, F dt) = 0;
+};
+
+// shared.rs:106-149 restated on the host (the same products in the same order: compile without FMA contraction and
+// a strict-math run through step_by_with equals the device-integrated run bit for bit)
+template <class F>
+struct LeapFrogIntegratorT : IntegratorT<F> {
+    void integrate_pre_force(std::vector<PointParticleT<F>>& points, F dt) override {
+        for (auto& p : points)
+            for (int k = 0; k < 3; ++k) p.position[k] += (p.velocity[k] * F(0.5)) * dt;          // :138
+    }
+    void integrate_after_force(std::vector<PointParticleT<F>>& points, F dt) override {
+        for (auto& p : points)
+            for (int k = 0; k < 3; ++k) {
+                p.velocity[k] += p.acceleration[k] * dt;                                          // :144
+                p.position[k] += (p.velocity[k] * F(0.5)) * dt;                                   // :146
+            }
+    }
+};
+
 template <class F>
 class SimulationT {
 public:
@@ -99,7 +129,35 @@ public:
         }
         return points_;
     }
-    F elapsed() const { F t = 0; check(abi::elapsed(h_, &t)); return t; }   // :94
+    // step_by with the integrator `I` of the caller's choice (the trait's generic parameter): brute_force.rs:84-90 /
+    // barnes_hut.rs:265-271 step by step -- pre-force on the host, retain (Bounds::contains, shared.rs:210-212: inclusive
+    // walls, NaN dropped, order kept), forces on the device, after-force on the host, elapsed += dt
+    void step_by_with(IntegratorT<F>& integrator, F dt) {
+        push_settings();
+        std::vector<Particle> pts = get_points();
+        integrator.integrate_pre_force(pts, dt);
+        const F hw = bounds_.width * F(0.5);
+        size_t kept = 0;
+        for (size_t i = 0; i < pts.size(); ++i) {
+            bool in = true;
+            for (int k = 0; k < 3; ++k) {
+                const F lo = bounds_.center[k] + (-hw), hi = bounds_.center[k] + hw;
+                if (!(pts[i].position[k] >= lo) || !(pts[i].position[k] <= hi)) in = false;
+            }
+            if (in) pts[kept++] = pts[i];
+        }
+        pts.resize(kept);
+        check(nbody_upload(h_, pts.data(), pts.size(), sizeof(Particle)));
+        check(nbody_update_forces(h_));
+        dirty_ = true;
+        pts = get_points();
+        integrator.integrate_after_force(pts, dt);
+        check(nbody_upload(h_, pts.data(), pts.size(), sizeof(Particle)));
+        points_ = std::move(pts);
+        dirty_ = false;
+        host_elapsed_ += dt;
+    }
+    F elapsed() const { F t = 0; check(abi::elapsed(h_, &t)); return t + host_elapsed_; }   // :94
     const SimulationSettingsT<F>& settings() const { return settings_; }    // :95
     SimulationSettingsT<F>& settings_mut() { settings_dirty_ = true; return settings_; }  // :96
     void sync() { check(nbody_sync(h_)); }
@@ -146,6 +204,7 @@ protected:
     SimulationSettingsT<F> settings_{};
     BoundsT<F> bounds_{};
     bool settings_dirty_ = true;
+    F host_elapsed_ = F(0);   // advanced by step_by_with (the device's clock only sees its own steps)
     mutable bool dirty_ = true;
     mutable std::vector<Particle> points_;
 };

@@ -287,6 +287,33 @@ impl<F: HipFloat, const METHOD: i32> HipSimulation<F, METHOD> {
         self.dirty.set(true);
     }
 
+    /// `step_by` with an integrator of the caller's choice -- the trait's generic parameter `I` (src/shared.rs:99-104).  The
+    /// device fuses the reference's `LeapFrogIntegrator` (the only one it ships) into its kernels: that is `step_by`.  Any
+    /// other `Integrator` runs here, on the host, as the unfused form of the same sequence (src/manual/brute_force.rs:84-90):
+    /// pre-force on the synced vector, retain, forces on the device, after-force, `elapsed += dt`.  (The C++ mirror's
+    /// `step_by_with` is this method; tests/test_cli.py shows a host leapfrog ending in the device's bits.)
+    pub fn step_by_with<J: Integrator<F, 3, P<F>>>(&mut self, integrator: &mut J, dt: F) {
+        self.push_settings();
+        let mut pts: Vec<P<F>> = self.get_points().clone();
+        integrator.integrate_pre_force(&mut pts, dt);
+        let bounds = self.bounds;
+        pts.retain(|p| bounds.contains(p.position())); // src/shared.rs:210-212: inclusive walls, NaN dropped, order kept
+        self.upload_points(&pts);
+        let rc = unsafe { nbody_update_forces(self.handle) };
+        self.check(rc);
+        self.dirty.set(true);
+        let mut pts: Vec<P<F>> = self.get_points().clone();
+        integrator.integrate_after_force(&mut pts, dt);
+        self.upload_points(&pts);
+        self.elapsed += dt;
+    }
+
+    fn upload_points(&mut self, pts: &[P<F>]) {
+        let rc = unsafe { nbody_upload(self.handle, pts.as_ptr() as *const c_void, pts.len(), std::mem::size_of::<P<F>>()) };
+        self.check(rc);
+        self.dirty.set(true);
+    }
+
     /// Blocks until everything enqueued has finished (call before reading a host clock).
     pub fn sync(&mut self) {
         let rc = unsafe { nbody_sync(self.handle) };

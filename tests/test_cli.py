@@ -37,3 +37,23 @@ def test_cli_reference_argv_and_output_lines(gpu, extra):
     assert m and float(m.group(1)) > 1.0
     left = int(re.search(r"Bodies left: (\d+)", out).group(1))
     assert 2500 <= left <= 3001
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--method", "bf", "--ic", "plummer", "--width", "3"], ["--method", "bh"], ["--dtype", "f64", "--method", "bh"]])
+def test_cli_generic_integrator_on_the_host_equals_the_fused_device_one(gpu, tmp_path, extra):
+    """The reference's trait is generic over its Integrator (src/shared.rs:99-104).  The device fuses the reference's
+    LeapFrogIntegrator into its kernels; any other integrator runs on the host through the mirror's step_by_with (the
+    unfused form of step_by: forces on the device, pre-/after-force and retain on the host).  With the leapfrog restated on
+    the host and strict arithmetic the two runs end in the same bits -- bodies leaving the box on the way."""
+    import numpy as np
+    dumps = []
+    for integ in ("device", "host"):
+        f = str(tmp_path / f"{integ}.bin")
+        r = subprocess.run([CLI, "-t", "2", "-n", "1200", "--steps", "12", "--math", "strict", "--integrator", integ, "--dump", f] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        dumps.append(np.fromfile(f, np.uint8))
+    assert len(dumps[0]) > 0 and np.array_equal(dumps[0], dumps[1])
+    if "--width" in extra:
+        assert len(dumps[0]) < 1200 * 40      # some bodies left the tight box

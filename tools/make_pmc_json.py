@@ -8,7 +8,7 @@ import os
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 commit = sys.argv[2] if len(sys.argv) > 2 else "?"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
@@ -22,8 +22,13 @@ def counter(section, kernel_sub):
         return None
     for line in m.group(1).splitlines():
         if kernel_sub in line:
+            global last_kernel_name
+            last_kernel_name = re.search(r"(%s[^>]*>)" % re.escape(kernel_sub), line).group(1)
             return float(line.split()[-1])
     return None
+
+
+last_kernel_name = None
 
 
 def bench(name):
@@ -39,7 +44,7 @@ def write(name, d):
 
 fz, wz = counter("pmc_fetch_bf", "k_bf_sym<"), counter("pmc_write_bf", "k_bf_sym<")
 write("pmc_traffic_bf.json", {
-    "kernel": "k_bf_sym<8,12,0,true>", "workload": "configs[1] N=65536 brute force, fast math, 1 GPU", "commit": commit,
+    "kernel": last_kernel_name, "workload": "configs[1] N=65536 brute force, fast math, 1 GPU", "commit": commit,
     "FETCH_SIZE_KiB_per_launch": fz, "WRITE_SIZE_KiB_per_launch": wz,
     "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for 16-B/lane streaming reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
     "hbm_bytes_per_launch": int(2 * fz * 1024 + wz * 1024),
@@ -52,7 +57,7 @@ for tree in ("host", "device"):
     b = bench(f"pmc_l1_bh_{tree}")
     visits = b["bh"]["node_visits_per_step"]
     write(f"pmc_traffic_bh_{tree}.json", {
-        "kernel": "k_bh_walk<true,false,false,64>", "workload": f"configs[2] N=65536 Barnes-Hut theta=0.5, fast math, {tree} tree, 1 GPU", "commit": commit,
+        "kernel": last_kernel_name, "workload": f"configs[2] N=65536 Barnes-Hut theta=0.5, fast math, {tree} tree, 1 GPU", "commit": commit,
         "FETCH_SIZE_KiB_per_launch": fz, "WRITE_SIZE_KiB_per_launch": wz,
         "correction": "FETCH_SIZE doubled as for streaming reads; the walk's reads are divergent 16-B gathers, a width the guide calls uncalibrated, so treat the figure as +-2x",
         "hbm_bytes_per_launch": int(2 * fz * 1024 + wz * 1024),

@@ -5,7 +5,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/profile_all.sh r02'
 # Outputs land in gpurun_out/prof_<tag>/ as text; tools/make_pmc_json.py turns them into profiles/*.json.
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of one emulated rank of a world of G (tools/tune_sharded.py): the per-rank kernel chain of a
 # sharded brute-force step.   gpurun --timeout 600 -- 'bash tools/profile_sharded.sh r02 8'
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 G=${2:-8}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG

@@ -21,12 +21,12 @@ ap.add_argument("--ipt", default="0")
 ap.add_argument("--slots", default="3072")
 ap.add_argument("--wpb", default="4")
 ap.add_argument("--steps", type=int, default=40)
-ap.add_argument("--sym-wpb", default="12", help="own-shard kernel: waves per workgroup (8, 12, 16)")
+ap.add_argument("--sym-wpb", default="4", help="own-shard kernel: waves per workgroup (4, 8, 12, 16)")
 ap.add_argument("--sym-rounds", default="1")
 ap.add_argument("--reduce-split", type=int, default=1, help="0: the one-thread-per-body plane reduction of round 1")
 a = ap.parse_args()
-nb = graft.load_package(tuning=True)   # (the build with the experimental walks and the in-kernel stamps)
-knob = {k: knob(nb, f"cross_{k}") for k in ("ipt", "slots", "wpb")}
+nb = graft.load_package()
+cross = {k: knob(nb, f"cross_{k}") for k in ("ipt", "slots", "wpb")}
 sym_wpb, sym_rounds = knob(nb, "sym_wpb"), knob(nb, "sym_rounds")
 knob(nb, "sym_reduce_split").value = a.reduce_split
 ics = nb.plummer(a.n)
@@ -36,7 +36,7 @@ for sw, sr in [(int(x), int(y)) for x in a.sym_wpb.split(",") for y in a.sym_rou
       for ipt in [int(x) for x in a.ipt.split(",")]:
           for slots in [int(x) for x in a.slots.split(",")]:
               for wpb in [int(x) for x in a.wpb.split(",")]:
-                  knob["ipt"].value, knob["slots"].value, knob["wpb"].value = ipt, slots, wpb
+                  cross["ipt"].value, cross["slots"].value, cross["wpb"].value = ipt, slots, wpb
                   sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST, rank=0, world_size=G, capacity=a.n)
                   sim.settings = nb.Settings(1.0, 1e-2, 1e-3, 0.5)
                   for _ in range(3):
@@ -52,5 +52,4 @@ for sw, sr in [(int(x), int(y)) for x in a.sym_wpb.split(",") for y in a.sym_rou
                   print(f"sym_wpb={sw} rounds={sr} G={G} n_own={a.n // G} ipt={ipt} slots={slots} wpb={wpb}: dominant kernel {k_ms:.4f} ms "
                         f"({s.force_kernel_interactions / max(1, s.force_launches) / max(k_ms, 1e-9) / 1e9:.2f} T inter/s), step wall {wall:.4f} ms", flush=True)
                   sim.close()
-knob["ipt"].value, knob["slots"].value, knob["wpb"].value = 0, 3072, 4
-sym_wpb.value, sym_rounds.value = 12, 1
+
