@@ -79,9 +79,9 @@ template <class P4, class Real>
 __global__ __launch_bounds__(256) void k_tree_keys(const P4* __restrict__ pos, const int* __restrict__ count,
                                                    int n_upper, Real cx0, Real cy0, Real cz0, Real width,
                                                    unsigned long long* __restrict__ keys, int* __restrict__ ids,
-                                                   int* __restrict__ out_info) {
+                                                   int* __restrict__ out_info, int* __restrict__ counters) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k == 0) { out_info[0] = 0; out_info[1] = 0; }  // node count and flags of this build (first kernel of the build)
+    if (k == 0) { out_info[0] = 0; out_info[1] = 0; counters[0] = 0; counters[1] = 0; }  // node count and flags of this build; k_tree_ties' list length and finished blocks (first kernel of the build)
     if (k >= n_upper) return;
     if (k >= *count) {  // n_upper only bounds the live count: the unused tail sorts to the end (bit 63 set),
         keys[k] = ~0ull;  // where every later kernel ignores it (they all read *count)
@@ -110,15 +110,15 @@ __device__ __forceinline__ int common_levels2(const unsigned long long* __restri
 // (insertion sort; the radix sort is stable, so equal keys keep ascending ids), and inside it every run of equal FULL
 // keys gets its second keys (levels 21..41) and is put in their order.  Groups are pairs in practice.  A group of more
 // than kMaxLowGroup bodies (a dense clump inside one level-16 cell, 1e-3 of a width-64 box) is not sorted by one thread:
-// its bounds go on a list and k_tree_big_groups sorts it with a workgroup (up to kMaxBigGroup bodies, kMaxBigGroups
-// groups per build).  Beyond that -- and for a run of more than tuning().tree_max_tie (64) equal FULL keys -- the build
+// its bounds go on a list and the last workgroup of k_tree_ties sorts it (sort_big_groups: up to kMaxBigGroup bodies,
+// kMaxBigGroups groups per build).  Beyond that -- and for a run of more than tuning().tree_max_tie (64) equal FULL keys -- the build
 // raises a flag: 1 = "deeper than the build's 42 levels", 4 = "a clump larger than the build sorts" (the single-GPU step
 // then builds on the host; a spatial rank reports it as what it is).
 constexpr int kSortLowBits = 15;    // key bits the radix sort leaves to k_tree_ties (levels 16..20)
 constexpr int kMaxLowGroup = 256;
 constexpr int kBigItems = 16;
 constexpr int kMaxBigGroup = 256 * kBigItems;   // 4096 bodies: one workgroup's block_radix_sort
-constexpr int kMaxBigGroups = 255;              // list entries {begin, end} behind the counter
+constexpr int kMaxBigGroups = 256;              // list entries {begin, end}
 
 // runs of equal FULL keys inside the sorted group [a0, e): second keys (levels 21..41), put in their order
 template <class P4, class Real>
@@ -142,47 +142,17 @@ __device__ void finish_equal_key_runs(const P4* __restrict__ pos, Real cx0, Real
     }
 }
 
+// the listed groups (257 .. 4096 bodies sharing 16 levels), one after the other by ONE workgroup -- the last one of
+// k_tree_ties to finish (no launch of its own: the list is empty in all but pathological worlds): a stable block radix
+// sort on the 15 low key bits (the group's top bits are equal), then the runs of equal full keys as above
 template <class P4, class Real>
-__global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, const int* __restrict__ count, Real cx0, Real cy0,
-                                                   Real cz0, Real width, unsigned long long* __restrict__ keys,
-                                                   unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
-                                                   int kMaxTie, int* __restrict__ big_list /* [0] = count, then {begin, end} pairs */) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int n = *count;
-    if (j + 1 >= n) return;
-    const unsigned long long top = keys[j] >> kSortLowBits;
-    if ((keys[j + 1] >> kSortLowBits) != top || (j > 0 && (keys[j - 1] >> kSortLowBits) == top)) return;
-    int e = j + 2;
-    while (e < n && e - j <= kMaxBigGroup && (keys[e] >> kSortLowBits) == top) ++e;
-    if (e - j > kMaxLowGroup) {
-        if (e - j > kMaxBigGroup) { atomicOr(flags, 4); return; }
-        const int slot = atomicAdd(big_list, 1);
-        if (slot >= kMaxBigGroups) { atomicOr(flags, 4); return; }
-        big_list[1 + 2 * slot] = j;
-        big_list[2 + 2 * slot] = e;
-        return;
-    }
-    for (int q = j + 1; q < e; ++q) {           // by the full key
-        const unsigned long long k = keys[q];
-        const int id = ids[q];
-        int r = q - 1;
-        while (r >= j && keys[r] > k) { keys[r + 1] = keys[r]; ids[r + 1] = ids[r]; --r; }
-        keys[r + 1] = k; ids[r + 1] = id;
-    }
-    finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, j, e, flags, kMaxTie);
-}
-
-// the listed groups (257 .. 4096 bodies sharing 16 levels), one workgroup each: a stable block radix sort on the 15 low
-// key bits (the group's top bits are equal), then the runs of equal full keys as above
-template <class P4, class Real>
-__global__ __launch_bounds__(256) void k_tree_big_groups(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width,
-                                                         unsigned long long* __restrict__ keys, unsigned long long* __restrict__ keys2,
-                                                         int* __restrict__ ids, int* __restrict__ flags, int kMaxTie, const int* __restrict__ big_list) {
+__device__ void sort_big_groups(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width, unsigned long long* __restrict__ keys,
+                                unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags, int kMaxTie,
+                                const int* __restrict__ big_list, int n_groups) {
     using Sort = rocprim::block_radix_sort<unsigned long long, 256, kBigItems, int>;
     __shared__ typename Sort::storage_type storage;
-    const int n_groups = min(big_list[0], kMaxBigGroups);
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const int b = big_list[1 + 2 * g], e = big_list[2 + 2 * g];
+    for (int g = 0; g < n_groups; ++g) {
+        const int b = big_list[2 * g], e = big_list[2 * g + 1];
         unsigned long long k[kBigItems];
         int v[kBigItems];
 #pragma unroll
@@ -201,6 +171,56 @@ __global__ __launch_bounds__(256) void k_tree_big_groups(const P4* __restrict__ 
         __syncthreads();
         if (threadIdx.x == 0) finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, b, e, flags, kMaxTie);
         __syncthreads();
+    }
+}
+
+template <class P4, class Real>
+__global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, const int* __restrict__ count, Real cx0, Real cy0,
+                                                   Real cz0, Real width, unsigned long long* __restrict__ keys,
+                                                   unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
+                                                   int kMaxTie, int* __restrict__ big_list /* {begin, end} pairs */,
+                                                   int* __restrict__ counters /* [0] pairs listed, [1] workgroups finished */) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int n = *count;
+    bool leader = j + 1 < n;
+    unsigned long long top = 0;
+    if (leader) {
+        top = keys[j] >> kSortLowBits;
+        leader = (keys[j + 1] >> kSortLowBits) == top && !(j > 0 && (keys[j - 1] >> kSortLowBits) == top);
+    }
+    if (leader) {
+        int e = j + 2;
+        while (e < n && e - j <= kMaxBigGroup && (keys[e] >> kSortLowBits) == top) ++e;
+        if (e - j > kMaxLowGroup) {
+            if (e - j > kMaxBigGroup) atomicOr(flags, 4);
+            else {
+                const int slot = atomicAdd(&counters[0], 1);
+                if (slot >= kMaxBigGroups) atomicOr(flags, 4);
+                else { big_list[2 * slot] = j; big_list[2 * slot + 1] = e; }
+            }
+        } else {
+            for (int q = j + 1; q < e; ++q) {           // by the full key
+                const unsigned long long k = keys[q];
+                const int id = ids[q];
+                int r = q - 1;
+                while (r >= j && keys[r] > k) { keys[r + 1] = keys[r]; ids[r + 1] = ids[r]; --r; }
+                keys[r + 1] = k; ids[r + 1] = id;
+            }
+            finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, j, e, flags, kMaxTie);
+        }
+    }
+    // the last workgroup to get here sorts the listed groups (every other one has published its entries by then)
+    __shared__ int n_big;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(&counters[1], 1);
+        n_big = (done == int(gridDim.x) - 1) ? min(atomicAdd(&counters[0], 0), kMaxBigGroups) : 0;
+    }
+    __syncthreads();
+    if (n_big > 0) {
+        __threadfence();
+        sort_big_groups(pos, cx0, cy0, cz0, width, keys, keys2, ids, flags, kMaxTie, big_list, n_big);
     }
 }
 
@@ -565,6 +585,7 @@ struct BuildLayout {
     int *ids_in, *ids, *emit_count, *base, *wpre;
     signed char* delta;
     Sum4 *sums, *incl;
+    int* counters;   // [2] k_tree_ties: groups listed for the workgroup sort, workgroups finished (cleared by k_tree_keys)
 };
 BuildLayout build_layout(void* workspace, size_t n_cap) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -583,6 +604,7 @@ BuildLayout build_layout(void* workspace, size_t n_cap) {
     L.delta = reinterpret_cast<signed char*>(p); p += al(n_cap);
     L.sums = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
     L.incl = reinterpret_cast<Sum4*>(p); p += al(n_cap * sizeof(Sum4));
+    L.counters = reinterpret_cast<int*>(p);   // (the 256 bytes tree_build_workspace_bytes adds at the end)
     return L;
 }
 }  // namespace
@@ -597,17 +619,14 @@ int sort_keys_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, c
     const int n = n_upper;
     if (n <= 0) { (void)hipMemsetAsync(out_info, 0, 2 * sizeof(int), s); return 0; }  // (k_tree_keys clears it otherwise)
     hipLaunchKernelGGL((k_tree_keys<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, n, center[0], center[1], center[2], width,
-                       L.keys_in, L.ids_in, out_info);
+                       L.keys_in, L.ids_in, out_info, L.counters);
     size_t tb = L.tmp_bytes;
     // (bits [15, 63): the unused tail's keys are all ones and stay behind every real body -- the sort is stable and the
     // tail comes last in the input; k_tree_ties finishes the low bits)
     if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), kSortLowBits, 63, s) != hipSuccess) return -1;
     int* big_list = static_cast<int*>(L.tmp);   // (the sort is done with its scratch; the scans take it over after this)
-    (void)hipMemsetAsync(big_list, 0, sizeof(int), s);
     hipLaunchKernelGGL((k_tree_ties<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width,
-                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie), big_list);
-    hipLaunchKernelGGL((k_tree_big_groups<P4, Real>), dim3(16), dim3(256), 0, s, pos, center[0], center[1], center[2], width, L.keys, L.keys2, L.ids,
-                       out_info + 1, std::max(1, tuning().tree_max_tie), big_list);
+                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie), big_list, L.counters);
     return 0;
 }
 template <class P4>
