@@ -61,7 +61,7 @@ struct RankInfo {
 };
 struct Ctrl {
     uint64_t magic;
-    std::atomic<int> world, arrived, bar_count, bar_gen, left;
+    std::atomic<int> world, arrived, bar_count, bar_gen, left, closed;
     RankInfo rank[kMaxRanks];
     std::atomic<uint64_t> posted[kMaxRanks][kMaxRanks];    // [src][dst] descriptors the source's host has published
     std::atomic<uint64_t> consumed[kMaxRanks][kMaxRanks];  // [src][dst] descriptors the destination's host has read
@@ -187,13 +187,15 @@ public:
             timeout_s_ = std::min(timeout_s_, 5.0);
             for (int r = 0; r < world_; ++r)
                 if (r != rank_ && sent_[r] > 0) (void)host_wait([&] { return int(flag_load(c_->done[rank_][r]) - (unsigned int)sent_[r]) >= 0; });
-            timeout_s_ = keep;
+            // leave together (bounded): nobody closes a mapping while a peer's queues are busy, nobody frees a window a peer has mapped
+            c_->left.fetch_add(1, std::memory_order_acq_rel);
+            (void)host_wait([&] { return c_->left.load(std::memory_order_acquire) >= world_; });
             for (int r = 0; r < world_; ++r)
                 if (peer_ptr_[r] && !peer_same_process_[r]) (void)hipIpcCloseMemHandle(peer_ptr_[r]);
-            // nobody may unmap a window a peer still reads: leave together (bounded)
-            c_->left.fetch_add(1, std::memory_order_acq_rel);
-            timeout_s_ = std::min(timeout_s_, 5.0);
-            (void)host_wait([&] { return c_->left.load(std::memory_order_acquire) >= world_; });
+            for (void* p : stale_) (void)hipIpcCloseMemHandle(p);
+            c_->closed.fetch_add(1, std::memory_order_acq_rel);
+            (void)host_wait([&] { return c_->closed.load(std::memory_order_acquire) >= world_; });
+            timeout_s_ = keep;
         }
         if (win_) (void)hipFree(win_);
         for (void* p : graveyard_) (void)hipFree(p);
@@ -305,10 +307,10 @@ private:
         if (peer_gen_[r] == gen && peer_ptr_[r]) { *out = peer_ptr_[r]; return NBODY_OK; }
         RankInfo& pi = c_->rank[r];
         if (pi.win_gen.load(std::memory_order_acquire) != gen) return fail(NBODY_ERR_COMM, "ipc transport: window generation of rank " + std::to_string(r) + " moved under a message");
-        if (peer_ptr_[r] && !peer_same_process_[r]) {
-            (void)hipDeviceSynchronize();   // copies out of the old mapping may still be enqueued
-            (void)hipIpcCloseMemHandle(peer_ptr_[r]);
-        }
+        // The old mapping stays open until the transport goes (copies out of it may still be enqueued, and -- measured on
+        // this driver, profiles/r03_ipc_close_stall.txt -- a hipIpcCloseMemHandle while the ranks' queues are busy froze
+        // every process on the device for 40-60 s).  Windows grow geometrically: what is kept is less than the last one.
+        if (peer_ptr_[r] && !peer_same_process_[r]) stale_.push_back(peer_ptr_[r]);
         peer_ptr_[r] = nullptr;
         if (pi.pid == int(getpid())) {
             peer_ptr_[r] = reinterpret_cast<char*>(uintptr_t(pi.win_raw));
@@ -452,7 +454,8 @@ private:
     char* win_ = nullptr;
     size_t win_bytes_ = 0;
     uint64_t win_gen_ = 0;
-    std::vector<void*> graveyard_;
+    std::vector<void*> graveyard_;   // own windows that were outgrown (a peer may still have them mapped)
+    std::vector<void*> stale_;       // peers' outgrown windows, still mapped here
     uint64_t sent_[kMaxRanks] = {}, recvd_[kMaxRanks] = {};
     char* peer_ptr_[kMaxRanks] = {};
     uint64_t peer_gen_[kMaxRanks] = {};
