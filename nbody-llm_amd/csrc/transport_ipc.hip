@@ -22,6 +22,11 @@
 // Ranks may also be THREADS of one process (the tests run 8 ranks as 4 x 2: a GPU box admits six GPU processes); then
 // every stream needs its own hardware queue (GPU_MAX_HW_QUEUES >= 2 per rank + 2): streams folded onto one queue run in
 // submission order, and a device-side wait of one rank would sit in front of the kernel of the other it waits for.
+// Windows and mappings outlive the transports (struct Arena below): on this driver, unmapping a peer's window
+// (hipIpcCloseMemHandle) or freeing an exported one, with other ranks' queues busy then or soon after, froze every process on
+// the device for 30-60 s (profiles/r03_ipc_close_stall.txt).  So neither ever happens: an exported window goes back to a
+// process-wide pool when its transport is done with it and serves the next transport of the process; a mapped window stays
+// mapped, and is found again by its handle.  The process's exit takes them all.
 #include "transport.h"
 #include "../../include/nbody_hip.h"
 
@@ -32,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <mutex>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
@@ -61,7 +67,7 @@ struct RankInfo {
 };
 struct Ctrl {
     uint64_t magic;
-    std::atomic<int> world, arrived, bar_count, bar_gen, left, closed;
+    std::atomic<int> world, arrived, bar_count, bar_gen;
     RankInfo rank[kMaxRanks];
     std::atomic<uint64_t> posted[kMaxRanks][kMaxRanks];    // [src][dst] descriptors the source's host has published
     std::atomic<uint64_t> consumed[kMaxRanks][kMaxRanks];  // [src][dst] descriptors the destination's host has read
@@ -129,6 +135,55 @@ __global__ void k_ipc_copy(CopyList l) {
     }
 }
 
+// ---- process-wide: exported windows (reused, never freed) and mapped peer windows (never unmapped); see the header
+struct Arena {
+    struct Win { char* p; size_t bytes; int device; hipIpcMemHandle_t handle; bool busy; };
+    struct Map { hipIpcMemHandle_t handle; int device; char* p; };
+    std::mutex m;
+    std::vector<Win> wins;
+    std::vector<Map> maps;
+
+    // a window of at least `bytes` on `device` (the smallest idle one that fits, else a new allocation)
+    hipError_t acquire(int device, size_t bytes, char** p, size_t* got, hipIpcMemHandle_t* handle) {
+        std::lock_guard<std::mutex> lock(m);
+        Win* best = nullptr;
+        for (Win& w : wins)
+            if (!w.busy && w.device == device && w.bytes >= bytes && (!best || w.bytes < best->bytes)) best = &w;
+        if (!best) {
+            void* fresh = nullptr;
+            hipError_t e = hipMalloc(&fresh, bytes);
+            if (e != hipSuccess) return e;
+            Win w{static_cast<char*>(fresh), bytes, device, {}, false};
+            e = hipIpcGetMemHandle(&w.handle, fresh);
+            if (e != hipSuccess) { (void)hipFree(fresh); return e; }   // (never exported: freeing it is harmless)
+            wins.push_back(w);
+            best = &wins.back();
+        }
+        best->busy = true;
+        *p = best->p; *got = best->bytes; *handle = best->handle;
+        return hipSuccess;
+    }
+    void release(char* p) {
+        std::lock_guard<std::mutex> lock(m);
+        for (Win& w : wins) if (w.p == p) w.busy = false;
+    }
+    hipError_t open(int device, const hipIpcMemHandle_t& handle, char** p) {
+        std::lock_guard<std::mutex> lock(m);
+        for (const Map& k : maps)
+            if (k.device == device && std::memcmp(&k.handle, &handle, sizeof(handle)) == 0) { *p = k.p; return hipSuccess; }
+        void* q = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&q, handle, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return e;
+        maps.push_back(Map{handle, device, static_cast<char*>(q)});
+        *p = static_cast<char*>(q);
+        return hipSuccess;
+    }
+};
+Arena& arena() {
+    static Arena* a = new Arena;   // (never destroyed: transports of static-lifetime handles may still release into it at exit)
+    return *a;
+}
+
 using clk = std::chrono::steady_clock;
 
 double timeout_seconds() {
@@ -182,23 +237,14 @@ public:
     ~IpcTransport() override {
         if (c_ && joined_) {
             (void)hipDeviceSynchronize();
-            // the own window goes only when every receiver is done with what was sent (a dead peer: a short wait)
+            // the own window serves another transport only when every receiver is done with what was sent (a dead peer: a short wait)
             const double keep = timeout_s_;
             timeout_s_ = std::min(timeout_s_, 5.0);
             for (int r = 0; r < world_; ++r)
                 if (r != rank_ && sent_[r] > 0) (void)host_wait([&] { return int(flag_load(c_->done[rank_][r]) - (unsigned int)sent_[r]) >= 0; });
-            // leave together (bounded): nobody closes a mapping while a peer's queues are busy, nobody frees a window a peer has mapped
-            c_->left.fetch_add(1, std::memory_order_acq_rel);
-            (void)host_wait([&] { return c_->left.load(std::memory_order_acquire) >= world_; });
-            for (int r = 0; r < world_; ++r)
-                if (peer_ptr_[r] && !peer_same_process_[r]) (void)hipIpcCloseMemHandle(peer_ptr_[r]);
-            for (void* p : stale_) (void)hipIpcCloseMemHandle(p);
-            c_->closed.fetch_add(1, std::memory_order_acq_rel);
-            (void)host_wait([&] { return c_->closed.load(std::memory_order_acquire) >= world_; });
             timeout_s_ = keep;
         }
-        if (win_) (void)hipFree(win_);
-        for (void* p : graveyard_) (void)hipFree(p);
+        if (win_) arena().release(win_);
         if (registered_) (void)hipHostUnregister(c_);
         if (c_) (void)munmap(c_, ctrl_bytes());
     }
@@ -290,12 +336,13 @@ private:
                 return fail(NBODY_ERR_COMM, "ipc transport: rank " + std::to_string(r) + " never took message " + std::to_string(sent_[r]) + " of rank " + std::to_string(rank_));
         size_t bytes = std::max<size_t>(need + need / 2, size_t(1) << 20);
         bytes = (bytes + (size_t(2) << 20) - 1) / (size_t(2) << 20) * (size_t(2) << 20);
-        void* fresh = nullptr;
-        if (hipMalloc(&fresh, bytes) != hipSuccess) return fail(NBODY_ERR_HIP, "ipc transport: hipMalloc of the window failed");
+        char* fresh = nullptr;
         RankInfo& me = c_->rank[rank_];
-        if (hipIpcGetMemHandle(&me.win_handle, fresh) != hipSuccess) { (void)hipFree(fresh); return fail(NBODY_ERR_HIP, "ipc transport: hipIpcGetMemHandle failed"); }
-        if (win_) graveyard_.push_back(win_);   // (a peer may still have it mapped: freed with the transport)
-        win_ = static_cast<char*>(fresh);
+        hipIpcMemHandle_t handle;
+        if (arena().acquire(device_, bytes, &fresh, &bytes, &handle) != hipSuccess) return fail(NBODY_ERR_HIP, "ipc transport: no memory for the window (hipMalloc / hipIpcGetMemHandle failed)");
+        me.win_handle = handle;
+        if (win_) arena().release(win_);   // (everything sent from it has been taken: see the wait above)
+        win_ = fresh;
         win_bytes_ = bytes;
         me.win_raw = uint64_t(reinterpret_cast<uintptr_t>(fresh));
         me.win_bytes = bytes;
@@ -307,20 +354,12 @@ private:
         if (peer_gen_[r] == gen && peer_ptr_[r]) { *out = peer_ptr_[r]; return NBODY_OK; }
         RankInfo& pi = c_->rank[r];
         if (pi.win_gen.load(std::memory_order_acquire) != gen) return fail(NBODY_ERR_COMM, "ipc transport: window generation of rank " + std::to_string(r) + " moved under a message");
-        // The old mapping stays open until the transport goes (copies out of it may still be enqueued, and -- measured on
-        // this driver, profiles/r03_ipc_close_stall.txt -- a hipIpcCloseMemHandle while the ranks' queues are busy froze
-        // every process on the device for 40-60 s).  Windows grow geometrically: what is kept is less than the last one.
-        if (peer_ptr_[r] && !peer_same_process_[r]) stale_.push_back(peer_ptr_[r]);
-        peer_ptr_[r] = nullptr;
         if (pi.pid == int(getpid())) {
             peer_ptr_[r] = reinterpret_cast<char*>(uintptr_t(pi.win_raw));
-            peer_same_process_[r] = true;
         } else {
-            void* p = nullptr;
-            hipError_t e = hipIpcOpenMemHandle(&p, pi.win_handle, hipIpcMemLazyEnablePeerAccess);
-            if (e != hipSuccess) return fail(NBODY_ERR_HIP, std::string("ipc transport: hipIpcOpenMemHandle: ") + hipGetErrorString(e));
-            peer_ptr_[r] = static_cast<char*>(p);
-            peer_same_process_[r] = false;
+            const hipIpcMemHandle_t handle = pi.win_handle;
+            const hipError_t e = arena().open(device_, handle, &peer_ptr_[r]);   // (the mapping of the window it replaces stays: see the header)
+            if (e != hipSuccess) { peer_ptr_[r] = nullptr; return fail(NBODY_ERR_HIP, std::string("ipc transport: hipIpcOpenMemHandle: ") + hipGetErrorString(e)); }
         }
         peer_gen_[r] = gen;
         *out = peer_ptr_[r];
@@ -454,12 +493,9 @@ private:
     char* win_ = nullptr;
     size_t win_bytes_ = 0;
     uint64_t win_gen_ = 0;
-    std::vector<void*> graveyard_;   // own windows that were outgrown (a peer may still have them mapped)
-    std::vector<void*> stale_;       // peers' outgrown windows, still mapped here
     uint64_t sent_[kMaxRanks] = {}, recvd_[kMaxRanks] = {};
     char* peer_ptr_[kMaxRanks] = {};
     uint64_t peer_gen_[kMaxRanks] = {};
-    bool peer_same_process_[kMaxRanks] = {};
 };
 
 }  // namespace

@@ -21,7 +21,7 @@ for spec in sys.argv[1:]:
                "sim": {"method": "bh", "math": "fast", "shard": "spatial", "tree": "device"},
                "ics": {"kind": "plummer", "n": n, "seed": 20250523}, "box": [[0, 0, 0], 400.0],
                "settings": {"g": 1.0, "g_soft": 0.05, "dt": 1e-3, "theta2": 0.25},
-               "schedule": [["steps", steps]], "env": json.loads(os.environ.get("PROBE_ENV", "{}"))}
+               "schedule": json.loads(os.environ["PROBE_SCHEDULE"]) if os.environ.get("PROBE_SCHEDULE") else [["steps", steps]], "env": json.loads(os.environ.get("PROBE_ENV", "{}"))}
         res = ranks.run_world(cfg, timeout=600)
         if cfg["env"].get("NBODY_LET_TRACE"):
             for g in range(cfg["world"]):
