@@ -14,6 +14,7 @@ struct Tuning {
     int cross_sym = 1;          // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided  [NBODY_CROSS_SYM]
     int sym_packed = 1;         // 1: packed-fp32 pair evaluation (pair_evals_pk), 0: scalar                                       [NBODY_SYM_PACKED]
     int bf_fast_variant = 0;    // 0: symmetric kernels where they apply, 1..: the LDS-tiled one-sided forms (kernels_bf.hip)       [NBODY_BF_VARIANT]
+    int let_list_div = 4;       // spatial shards: export / import buffers start at (slice node capacity) / this (they grow when a step needs more)
     int sym_wpb = 4;            // k_bf_sym: waves per workgroup: 4 (default), 8, 12 or 16                                           [NBODY_SYM_WPB]
     int sym_rounds = 1;         // k_bf_sym: rounds of workgroups per CU
     int sym_k = 0;              // k_bf_sym: waves (slices) per resident set; 0 = by the plan's rule

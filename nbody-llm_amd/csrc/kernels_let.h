@@ -43,8 +43,8 @@ struct RoundB {                 // what every rank tells the others after its sc
     Contrib c[kMaxRanks][kLevels];
 };
 
-struct LetRecord {              // an exported node (32 bytes): the record; b.z (NodeB::hot, which the plain walk does not read)
-    float4 a, b;                // carries its index in the global array
+struct LetRecord {              // an exported node (32 bytes): the record with its GLOBAL skip link; b.z (NodeB::hot, which the
+    float4 a, b;                // plain walk does not read) carries its global index (its place in the world's pre-order)
 };
 
 void launch_classify(hipStream_t s, const Shard& sh, int n_upper, const float center[3], float width, const unsigned long long* bounds,
@@ -69,14 +69,25 @@ void launch_ends(hipStream_t s, const Shard& sh, int n_upper, const unsigned lon
 void launch_edges(hipStream_t s, const EndInfo* ends, int G, int me, int* edge);
 void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const int* info, const EndInfo* ends, const int* edge, int G, int me,
                     RoundB* mine, bool balance_by_work, const int* own_flags);
-void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds);
-void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
-                     const int* offsets, int* top_index);
-void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const int* edge, const float4* global_nodes, const int* offsets,
-                           const int* top_index, const EndInfo* ends, int G, int me, float theta2, const int* parent,
-                           const unsigned char* depth, unsigned int* upper_ok, int2* link, int* let_count, LetRecord* send,
-                           size_t send_stride, bool prune);
-void launch_scatter(hipStream_t s, const LetRecord* recv, int n, float4* global_nodes, int global_cap);
+void launch_offsets(hipStream_t s, const RoundB* rb, int G, int* offsets, int* out_flags, unsigned long long* bounds);
+void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* slice, const int* offsets, int* top_index,
+                     float4* top_nodes);
+// the export lists, each in node order, one after the other in `send` (list r at list_first[r], let_count[r] long);
+// node_mask [local_cap], block_n [pack_blocks(local_cap) * kMaxRanks] hold what launch_pack needs to write them again into a
+// bigger buffer (records beyond send_cap are dropped: the counts tell)
+void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const int* edge, const float4* slice, const float4* top_nodes,
+                           const int* offsets, const int* top_index, const EndInfo* ends, int G, int me, float theta2, const int* parent,
+                           const unsigned char* depth, unsigned int* upper_ok, int2* link, unsigned int* node_mask, int* block_n, int* let_count,
+                           int* list_first, LetRecord* send, size_t send_cap, bool prune);
+void launch_pack(hipStream_t s, int local_cap, const int* info, const float4* slice, const float4* top_nodes, const int* offsets, const int* top_index,
+                 const unsigned char* depth, const unsigned int* node_mask, const int* block_first, const int* list_first, int G, int me, LetRecord* send,
+                 size_t send_cap);
+size_t pack_blocks(int local_cap);
+// the array the walk runs over: the rank's slice and the staged imports (in_n[q] records from rank q, one rank after the
+// other) in global-index order, links translated to positions; split = {0, nodes held}.  staged_upper >= the imports' total.
+void launch_assemble(hipStream_t s, const float4* slice, int local_cap, const LetRecord* staged, int staged_upper, const int* in_n, const int* info,
+                     const int* offsets, const int* top_index, const float4* top_nodes, int G, int me, void* layout, int* split, float4* held);
+size_t layout_bytes();
 
 }  // namespace let
 }  // namespace nbody

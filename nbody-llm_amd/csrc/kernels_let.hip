@@ -20,7 +20,8 @@
 //     there, i.e. if it can OPEN every ancestor: k_let_open_masks / k_let_flag_pack test the ancestors against the
 //     boxes the partners' bodies lie in (opening test of barnes_hut.rs:192 with the box's nearest point) and write one
 //     list of records per partner,
-//     one variable-size send/recv round, k_let_scatter drops them at their global indices in the receiver's array.
+//     one variable-size send/recv round; the receiver lays the nodes it HOLDS -- its slice and the imports -- out in the order
+//     of their global indices and turns every link into a position in that order (launch_assemble).
 // The walk (k_bh_walk) then runs over that array as over a complete tree: every node a body visits is there.
 // Fast math, device build; node values come from f64 prefix sums over the LOCAL sorted order, so against the single-shard
 // device build a centre of mass can differ in its last f32 bit (counts agree to ~1e-6, tested).
@@ -353,13 +354,14 @@ __global__ __launch_bounds__(64) void k_let_contrib(const unsigned long long* __
 
 // ---- after the all-gather of the RoundB records
 // offsets[r] = first global index of rank r's slice, offsets[G] = total
-__global__ void k_let_offsets(const RoundB* __restrict__ rb, int G, int global_cap, int* __restrict__ offsets, int* __restrict__ out_flags,
+__global__ void k_let_offsets(const RoundB* __restrict__ rb, int G, int* __restrict__ offsets, int* __restrict__ out_flags,
                               unsigned long long* __restrict__ bounds) {
     if (threadIdx.x != 0) return;
-    int run = 0, fl = 0;
-    for (int q = 0; q < G; ++q) { offsets[q] = run; run += rb[q].n_nodes; fl |= rb[q].flags; }
-    offsets[G] = run;
-    if (run > global_cap) fl |= kFlagNodeCap;
+    long long run = 0;
+    int fl = 0;
+    for (int q = 0; q < G; ++q) { offsets[q] = int(run); run += rb[q].n_nodes; fl |= rb[q].flags; }
+    offsets[G] = int(run);
+    if (run > 0x7fffffffLL) fl |= kFlagNodeCap;   // (global node indices are 32-bit)
     if (fl) atomicOr(out_flags, fl);
     // the bounds the NEXT classification uses (this step's is done): whoever held quantile j reported its key
     unsigned long long prev = 0ull;
@@ -372,16 +374,18 @@ __global__ void k_let_offsets(const RoundB* __restrict__ rb, int G, int global_c
     }
     bounds[G] = 1ull << 63;
 }
-// top[r][d] = the finished spanning cells (after the emit of my slice: it overwrites the ones that are mine)
+// top[r][d] = the finished spanning cells: their records (GLOBAL skip links) go to a small table every rank holds,
+// top_nodes[r * kLevels + d]; my own ones also get their finished centre of mass in my slice (after its emit), which the
+// opening masks below read.  top_index[r][d] = the cell's global index, -1: none.
 __global__ __launch_bounds__(64) void k_let_finalize(const RoundB* __restrict__ rb, const EndInfo* __restrict__ ends, int G, int me,
-                                                     float width, float4* __restrict__ global_nodes, int global_cap,
-                                                     const int* __restrict__ offsets, int* __restrict__ top_index /* [G][kLevels] global index or -1 */) {
+                                                     float width, float4* __restrict__ slice, const int* __restrict__ offsets,
+                                                     int* __restrict__ top_index /* [G][kLevels] */, float4* __restrict__ top_nodes /* [G][kLevels][2] */) {
     const int r = blockIdx.x, d = threadIdx.x;
     if (d >= kLevels) return;
     const int total = offsets[G];
     const Contrib own = rb[r].c[r][d];
     int gi = -1;
-    if (own.base_after >= 0 && total <= global_cap) {
+    if (own.base_after >= 0) {
         double m = own.m, mx = own.mx, my = own.my, mz = own.mz;
         int skip = total;
         for (int q = r + 1; q < G; ++q) {     // the later ranks, in order, until one still has a body beyond the cell
@@ -393,8 +397,10 @@ __global__ __launch_bounds__(64) void k_let_finalize(const RoundB* __restrict__ 
         float w = width;
         for (int q = 0; q < d; ++q) w = w * 0.5f;    // create_orthant halves the width exactly
         gi = offsets[r] + own.base_after;
-        global_nodes[2 * gi] = make_float4(float(mx / m), float(my / m), float(mz / m), float(m));
-        global_nodes[2 * gi + 1] = make_float4(w * w, __int_as_float(skip), __int_as_float(0), __int_as_float(-1));
+        const float4 A = make_float4(float(mx / m), float(my / m), float(mz / m), float(m));
+        top_nodes[2 * (r * kLevels + d)] = A;
+        top_nodes[2 * (r * kLevels + d) + 1] = make_float4(w * w, __int_as_float(skip), __int_as_float(gi), __int_as_float(-1));
+        if (r == me) slice[2 * own.base_after] = A;
     }
     top_index[r * kLevels + d] = gi;
 }
@@ -403,24 +409,24 @@ __global__ __launch_bounds__(64) void k_let_finalize(const RoundB* __restrict__ 
 // upper_ok[d] = bit mask of the partners that can open EVERY spanning cell on my first body's path from the root down
 // to depth d (those cells belong to earlier ranks); upper_ok[-1] := all.  One thread per (partner, child-cell box): its
 // box sits in registers while the block goes down the <= 21 cells.
-__global__ __launch_bounds__(kMaxRanks * kBoxes) void k_let_upper(const float4* __restrict__ global_nodes, const int* __restrict__ top_index,
+__global__ __launch_bounds__(kMaxRanks * kBoxes) void k_let_upper(const float4* __restrict__ top_nodes, const int* __restrict__ top_index,
                                                                   const EndInfo* __restrict__ ends, const int* __restrict__ edge, int G, int me,
                                                                   float theta2, unsigned int* __restrict__ upper_ok) {
     __shared__ unsigned int cell_ok[kLevels];   // partners that could open the spanning cell of depth d above my first body
-    __shared__ int cell_gi[kLevels];
+    __shared__ int cell_ti[kLevels];            // its place in top_nodes, -1: none
     const int r = threadIdx.x / kBoxes, b = threadIdx.x % kBoxes;
     const int e0 = edge[0];
     if (threadIdx.x < kLevels) {
         const int d = threadIdx.x;
         cell_ok[d] = 0u;
-        int gi = -1;
+        int ti = -1;
         if (d <= e0) {   // the cell of depth d that contains my first body: one of the spanning cells of an earlier rank
             const unsigned long long fk = ends[me].first_key;
-            for (int q = 0; q < me && gi < 0; ++q)
+            for (int q = 0; q < me && ti < 0; ++q)
                 if (top_index[q * kLevels + d] >= 0 && ends[q].n_bodies > 0 && prefix_lo(ends[q].last_key, d) == prefix_lo(fk, d))
-                    gi = top_index[q * kLevels + d];
+                    ti = q * kLevels + d;
         }
-        cell_gi[d] = gi;
+        cell_ti[d] = ti;
     }
     __syncthreads();
     const bool partner = r < G && r != me && ends[r].n_bodies > 0;
@@ -428,22 +434,22 @@ __global__ __launch_bounds__(kMaxRanks * kBoxes) void k_let_upper(const float4* 
     if (partner) for (int c = 0; c < 3; ++c) { lo[c] = ends[r].box_lo[b][c]; hi[c] = ends[r].box_hi[b][c]; }
     if (partner && lo[0] <= hi[0])
         for (int d = 0; d <= e0 && d < kLevels; ++d) {
-            const int gi = cell_gi[d];
-            if (gi >= 0 && box_could_open(global_nodes[2 * gi], global_nodes[2 * gi + 1].x, lo, hi, theta2)) atomicOr(&cell_ok[d], 1u << r);
+            const int ti = cell_ti[d];
+            if (ti >= 0 && box_could_open(top_nodes[2 * ti], top_nodes[2 * ti + 1].x, lo, hi, theta2)) atomicOr(&cell_ok[d], 1u << r);
         }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int mask = 0;
         for (int q = 0; q < G; ++q) if (q != me && ends[q].n_bodies > 0) mask |= 1u << q;
-        for (int d = 0; d < kLevels; ++d) { if (cell_gi[d] >= 0) mask &= cell_ok[d]; upper_ok[d] = mask; }
+        for (int d = 0; d < kLevels; ++d) { if (cell_ti[d] >= 0) mask &= cell_ok[d]; upper_ok[d] = mask; }
     }
 }
 
 // link[i] = {parent of my node i, the partners that could open it (0 for a leaf)}: one pass over the slice, so that the
 // ancestor walk below only ANDs words (testing every ancestor of every node against the boxes was 2 ms at 776 000 nodes).
 // The partners' non-empty boxes are staged in LDS once per block.
-__global__ __launch_bounds__(256) void k_let_open_masks(const float4* __restrict__ global_nodes, const int* __restrict__ offsets,
-                                                        const int* __restrict__ info, const EndInfo* __restrict__ ends, int G, int me,
+__global__ __launch_bounds__(256) void k_let_open_masks(const float4* __restrict__ slice, const int* __restrict__ info,
+                                                        const EndInfo* __restrict__ ends, int G, int me,
                                                         float theta2, const int* __restrict__ parent, int2* __restrict__ link) {
     __shared__ float outer[kMaxRanks][6];
     __shared__ float sub[kMaxRanks][kBoxes][6];
@@ -463,11 +469,10 @@ __global__ __launch_bounds__(256) void k_let_open_masks(const float4* __restrict
     __syncthreads();
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= info[0]) return;
-    const int gi = offsets[me] + idx;
-    const float4 B = global_nodes[2 * gi + 1];
+    const float4 B = slice[2 * idx + 1];
     unsigned int mask = 0;
     if (__float_as_int(B.w) < 0) {      // a cell
-        const float4 A = global_nodes[2 * gi];
+        const float4 A = slice[2 * idx];
         for (int r = 0; r < G; ++r) {
             if (r == me || n_sub[r] == 0) continue;
             if (!box_could_open(A, B.x, &outer[r][0], &outer[r][3], theta2)) continue;
@@ -479,25 +484,25 @@ __global__ __launch_bounds__(256) void k_let_open_masks(const float4* __restrict
     link[idx] = make_int2(parent[idx], int(mask));
 }
 
-// A node goes to partner r if r could open every one of its ancestors.  The lists are filled in whatever order the blocks
-// arrive (the receiver scatters by index); a block takes its slots of a list with ONE atomic (one per node and partner
-// was a million atomics on seven addresses).
+// A node goes to partner r if r could open every one of its ancestors; my own spanning cells go to everybody.  The lists
+// are written IN NODE ORDER (the receiver finds a node of a list by bisection on its global index): pass 1 works out every
+// node's partners and counts them per block of 1 024 nodes, one workgroup turns the counts into every block's first slot
+// in every list, pass 2 writes the records.
 constexpr int kPackThreads = 1024;
-__global__ __launch_bounds__(kPackThreads) void k_let_flag_pack(const float4* __restrict__ global_nodes, const int* __restrict__ offsets,
-                                                                const int* __restrict__ info, const unsigned char* __restrict__ depth,
-                                                                const int* __restrict__ top_index, const EndInfo* __restrict__ ends,
-                                                                const unsigned int* __restrict__ upper_ok, const int2* __restrict__ link,
-                                                                int G, int me, LetRecord* __restrict__ send, size_t send_stride,
-                                                                int* __restrict__ let_count) {
-    __shared__ int wave_n[kPackThreads / 64][kMaxRanks];   // records of each wave for each partner, then their first slot
+__global__ __launch_bounds__(kPackThreads) void k_let_flag_count(const int* __restrict__ offsets, const int* __restrict__ info,
+                                                                 const unsigned char* __restrict__ depth, const int* __restrict__ top_index,
+                                                                 const EndInfo* __restrict__ ends, const unsigned int* __restrict__ upper_ok,
+                                                                 const int2* __restrict__ link, int G, int me,
+                                                                 unsigned int* __restrict__ node_mask, int* __restrict__ block_n /* [blocks][kMaxRanks] */) {
+    __shared__ int wave_n[kPackThreads / 64][kMaxRanks];
     if (int(blockIdx.x) * kPackThreads >= info[0]) return;
     const int idx = blockIdx.x * kPackThreads + threadIdx.x;
     const int off = offsets[me];
     unsigned int mask = 0;
     if (idx < info[0]) {
+        for (int r = 0; r < G; ++r) if (r != me && ends[r].n_bodies > 0) mask |= 1u << r;
         const int d0 = depth[idx];
-        if (!(d0 < kLevels && top_index[me * kLevels + d0] == off + idx)) {   // (my own spanning cells are known to everybody already)
-            for (int r = 0; r < G; ++r) if (r != me && ends[r].n_bodies > 0) mask |= 1u << r;
+        if (!(d0 < kLevels && top_index[me * kLevels + d0] == off + idx)) {   // (a spanning cell of mine: everybody gets it, finished)
             int p = link[idx].x;
             while (mask != 0u && p != -1) {
                 if (p <= -2) { mask &= upper_ok[-p - 2]; break; }
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(kPackThreads) void k_let_flag_pack(const float4* __
                 p = l.x;
             }
         }
+        node_mask[idx] = mask;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = 0; r < G; ++r) {
@@ -513,38 +519,165 @@ __global__ __launch_bounds__(kPackThreads) void k_let_flag_pack(const float4* __
         if (lane == 0) wave_n[wave][r] = __popcll(vote);
     }
     __syncthreads();
-    if (int(threadIdx.x) < G) {          // thread r: the block's records for partner r -> one atomic, then every wave's first slot
-        const int r = threadIdx.x;
+    if (int(threadIdx.x) < G) {
         int total = 0;
-        for (int w = 0; w < kPackThreads / 64; ++w) total += wave_n[w][r];
-        int first = total > 0 ? atomicAdd(&let_count[r], total) : 0;
+        for (int w = 0; w < kPackThreads / 64; ++w) total += wave_n[w][threadIdx.x];
+        block_n[blockIdx.x * kMaxRanks + threadIdx.x] = total;
+    }
+}
+// block_n[b][r] -> the first slot of block b in list r (exclusive scan over the blocks, one partner after the other);
+// let_count[r] = the list's length
+// list_first[r] = where list r starts in the send buffer (the lists lie one after the other, each exactly as long as it is)
+__global__ __launch_bounds__(1024) void k_let_pack_scan(const int* __restrict__ info, int G, int* __restrict__ block_n, int* __restrict__ let_count,
+                                                        int* __restrict__ list_first /* [G + 1] */) {
+    __shared__ int part[1024][kMaxRanks];              // 64 KB: the threads' sums, all partners at once
+    const int n_blocks = (info[0] + kPackThreads - 1) / kPackThreads;
+    const int per = (n_blocks + 1023) / 1024;          // consecutive blocks per thread
+    const int b0 = threadIdx.x * per, b1 = min(n_blocks, b0 + per);
+    int sum[kMaxRanks];
+#pragma unroll
+    for (int r = 0; r < kMaxRanks; ++r) sum[r] = 0;
+    for (int b = b0; b < b1; ++b)
+#pragma unroll
+        for (int r = 0; r < kMaxRanks; ++r) if (r < G) sum[r] += block_n[b * kMaxRanks + r];
+#pragma unroll
+    for (int r = 0; r < kMaxRanks; ++r) part[threadIdx.x][r] = sum[r];
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1) {      // inclusive scan over the threads
+        int v[kMaxRanks];
+#pragma unroll
+        for (int r = 0; r < kMaxRanks; ++r) v[r] = (int(threadIdx.x) >= step) ? part[threadIdx.x - step][r] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kMaxRanks; ++r) part[threadIdx.x][r] += v[r];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < kMaxRanks; ++r) {
+        if (r >= G) continue;
+        int run = part[threadIdx.x][r] - sum[r];
+        for (int b = b0; b < b1; ++b) { const int c = block_n[b * kMaxRanks + r]; block_n[b * kMaxRanks + r] = run; run += c; }
+        if (threadIdx.x == 1023) let_count[r] = part[1023][r];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int r = 0; r < G; ++r) { list_first[r] = int(min(run, 0x7fffffffLL)); run += part[1023][r]; }
+        list_first[G] = int(min(run, 0x7fffffffLL));
+    }
+}
+__global__ __launch_bounds__(kPackThreads) void k_let_pack(const float4* __restrict__ slice, const int* __restrict__ offsets,
+                                                           const int* __restrict__ info, const unsigned char* __restrict__ depth,
+                                                           const int* __restrict__ top_index, const float4* __restrict__ top_nodes,
+                                                           const unsigned int* __restrict__ node_mask, const int* __restrict__ block_first,
+                                                           const int* __restrict__ list_first, int G, int me, LetRecord* __restrict__ send, size_t send_cap) {
+    __shared__ int wave_n[kPackThreads / 64][kMaxRanks];
+    if (int(blockIdx.x) * kPackThreads >= info[0]) return;
+    const int idx = blockIdx.x * kPackThreads + threadIdx.x;
+    const unsigned int mask = idx < info[0] ? node_mask[idx] : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = 0; r < G; ++r) {
+        const unsigned long long vote = __ballot((mask >> r) & 1u);
+        if (lane == 0) wave_n[wave][r] = __popcll(vote);
+    }
+    __syncthreads();
+    if (int(threadIdx.x) < G) {          // thread r: every wave's first slot in list r
+        const int r = threadIdx.x;
+        int first = list_first[r] + block_first[blockIdx.x * kMaxRanks + r];
         for (int w = 0; w < kPackThreads / 64; ++w) { const int c = wave_n[w][r]; wave_n[w][r] = first; first += c; }
     }
     __syncthreads();
     if (mask == 0u) return;
+    const int off = offsets[me];
     LetRecord rec;
-    rec.a = global_nodes[2 * (off + idx)]; rec.b = global_nodes[2 * (off + idx) + 1];
+    rec.a = slice[2 * idx]; rec.b = slice[2 * idx + 1];
+    const int d0 = depth[idx];
+    int skip = off + __float_as_int(rec.b.y);                      // the slice's links are local; the wire carries global ones
+    if (d0 < kLevels && top_index[me * kLevels + d0] == off + idx) skip = __float_as_int(top_nodes[2 * (me * kLevels + d0) + 1].y);
+    rec.b.y = __int_as_float(skip);
     rec.b.z = __int_as_float(off + idx);   // the slot of NodeB::hot carries the global index (the plain walk does not read it)
     for (int r = 0; r < G; ++r) {
         const bool mine = (mask >> r) & 1u;
         const unsigned long long vote = __ballot(mine);
         if (mine) {
             const size_t slot = size_t(wave_n[wave][r]) + size_t(__popcll(vote & ((1ull << lane) - 1ull)));
-            if (slot < send_stride) send[size_t(r) * send_stride + slot] = rec;
+            if (slot < send_cap) send[slot] = rec;   // (a buffer that is too small: the host sees it in the counts, grows it and packs again)
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_let_scatter(const LetRecord* __restrict__ recv, int n, float4* __restrict__ global_nodes,
-                                                     int global_cap) {
+// ---- the array the walk runs over: the nodes this rank HOLDS -- its slice and what the partners sent -- in the order of
+// their global indices, addressed by their position in that order.  in_n[q] = records received from rank q (in the staging
+// buffer one rank after the other, each list in node order); layout = {in_at[G], base[G], own_base, n_own, total}.
+// A link to global index t becomes the number of held nodes with a smaller index: exact when t is held -- and a node a
+// body can get to IS held (it is a child of a cell the body opened) -- and the next held node otherwise (a link nobody
+// follows).  A leaf's link is "the next node", which that rule keeps (the DIRECT walk tells leaves by it).
+struct HaloLayout { int in_at[kMaxRanks], base[kMaxRanks], own_base, n_own, total, pad; };
+__global__ void k_let_layout(const int* __restrict__ in_n, const int* __restrict__ info, int G, int me, HaloLayout* __restrict__ lay, int* __restrict__ split) {
+    if (threadIdx.x != 0) return;
+    int at = 0, pos = 0;
+    const int n_own = info[0];
+    for (int q = 0; q < G; ++q) {
+        if (q == me) { lay->own_base = pos; pos += n_own; lay->in_at[q] = at; lay->base[q] = lay->own_base; continue; }
+        lay->in_at[q] = at; lay->base[q] = pos;
+        at += in_n[q]; pos += in_n[q];
+    }
+    lay->n_own = n_own; lay->total = pos; lay->pad = 0;
+    split[0] = 0; split[1] = pos; split[2] = 0; split[3] = 0;
+}
+__device__ __forceinline__ int held_before(int t, const int* __restrict__ offsets, const int* __restrict__ in_n, const HaloLayout& lay,
+                                           const LetRecord* __restrict__ staged, int G, int me) {
+    int o = 0;
+    while (o < G && offsets[o + 1] <= t) ++o;       // the rank whose slice holds index t (G: t is the end of the tree)
+    if (o >= G) return lay.total;
+    if (o == me) return lay.own_base + (t - offsets[me]);
+    const LetRecord* list = staged + lay.in_at[o];
+    int a = 0, b = in_n[o];                          // first record of the list with global index >= t
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (__float_as_int(list[mid].b.z) >= t) b = mid; else a = mid + 1;
+    }
+    return lay.base[o] + a;
+}
+__global__ __launch_bounds__(256) void k_let_place_own(const float4* __restrict__ slice, const HaloLayout* __restrict__ lay_p, float4* __restrict__ held) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n_own = lay_p->n_own, base = lay_p->own_base;
+    if (idx >= n_own) return;
+    float4 B = slice[2 * idx + 1];
+    B.y = __int_as_float(__float_as_int(B.y) + base);
+    held[2 * size_t(base + idx)] = slice[2 * idx];
+    held[2 * size_t(base + idx) + 1] = B;
+}
+__global__ __launch_bounds__(256) void k_let_place_halo(const LetRecord* __restrict__ staged, const int* __restrict__ in_n,
+                                                        const int* __restrict__ offsets, const HaloLayout* __restrict__ lay_p, int G, int me,
+                                                        float4* __restrict__ held) {
+    __shared__ HaloLayout lay;
+    if (threadIdx.x == 0) lay = *lay_p;
+    __syncthreads();
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    LetRecord rec = recv[j];
-    const int index = __float_as_int(rec.b.z);
-    if (index < 0 || index >= global_cap) return;
+    if (j >= lay.total - lay.n_own) return;
+    int q = 0;                                       // the list record j belongs to
+    for (int r = 0; r < G; ++r) if (r != me && in_n[r] > 0 && lay.in_at[r] <= j) q = r;
+    LetRecord rec = staged[j];
+    const int pos = lay.base[q] + (j - lay.in_at[q]);
+    rec.b.y = __int_as_float(held_before(__float_as_int(rec.b.y), offsets, in_n, lay, staged, G, me));
     rec.b.z = __int_as_float(0);
-    global_nodes[2 * index] = rec.a;
-    global_nodes[2 * index + 1] = rec.b;
+    held[2 * size_t(pos)] = rec.a;
+    held[2 * size_t(pos) + 1] = rec.b;
+}
+// my own spanning cells: their links lead into later ranks' slices (after k_let_place_own, which gave them a local link)
+__global__ void k_let_place_top(const float4* __restrict__ top_nodes, const int* __restrict__ top_index, const LetRecord* __restrict__ staged,
+                                const int* __restrict__ in_n, const int* __restrict__ offsets, const HaloLayout* __restrict__ lay_p, int G, int me,
+                                float4* __restrict__ held) {
+    const int d = threadIdx.x;
+    if (d >= kLevels) return;
+    const int gi = top_index[me * kLevels + d];
+    if (gi < 0) return;
+    const HaloLayout lay = *lay_p;
+    const int pos = lay.own_base + (gi - offsets[me]);
+    float4 B = held[2 * size_t(pos) + 1];
+    B.y = __int_as_float(held_before(__float_as_int(top_nodes[2 * (me * kLevels + d) + 1].y), offsets, in_n, lay, staged, G, me));
+    held[2 * size_t(pos) + 1] = B;
 }
 
 inline dim3 grid_for(int n, int bs) { return dim3((std::max(n, 1) + bs - 1) / bs); }
@@ -597,29 +730,44 @@ void launch_contrib(hipStream_t s, const Shard& sh, const TreeDevWork& w, const 
     hipLaunchKernelGGL(k_let_contrib, dim3(G), dim3(64), 0, s, w.keys, w.delta, w.base, static_cast<const Sum4*>(w.incl), sh.own_count(), info,
                        ends, edge, G, me, mine, w.wpre, balance_by_work ? 1 : 0, own_flags);
 }
-void launch_offsets(hipStream_t s, const RoundB* rb, int G, int global_cap, int* offsets, int* out_flags, unsigned long long* bounds) {
-    hipLaunchKernelGGL(k_let_offsets, dim3(1), dim3(64), 0, s, rb, G, global_cap, offsets, out_flags, bounds);
+void launch_offsets(hipStream_t s, const RoundB* rb, int G, int* offsets, int* out_flags, unsigned long long* bounds) {
+    hipLaunchKernelGGL(k_let_offsets, dim3(1), dim3(64), 0, s, rb, G, offsets, out_flags, bounds);
 }
-void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* global_nodes, int global_cap,
-                     const int* offsets, int* top_index) {
-    hipLaunchKernelGGL(k_let_finalize, dim3(G), dim3(64), 0, s, rb, ends, G, me, width, global_nodes, global_cap, offsets, top_index);
+void launch_finalize(hipStream_t s, const RoundB* rb, const EndInfo* ends, int G, int me, float width, float4* slice, const int* offsets, int* top_index,
+                     float4* top_nodes) {
+    hipLaunchKernelGGL(k_let_finalize, dim3(G), dim3(64), 0, s, rb, ends, G, me, width, slice, offsets, top_index, top_nodes);
 }
-void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const int* edge, const float4* global_nodes, const int* offsets,
-                           const int* top_index, const EndInfo* ends, int G, int me, float theta2, const int* parent,
-                           const unsigned char* depth, unsigned int* upper_ok, int2* link, int* let_count, LetRecord* send,
-                           size_t send_stride, bool prune) {
+void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const int* edge, const float4* slice, const float4* top_nodes,
+                           const int* offsets, const int* top_index, const EndInfo* ends, int G, int me, float theta2, const int* parent,
+                           const unsigned char* depth, unsigned int* upper_ok, int2* link, unsigned int* node_mask, int* block_n, int* let_count,
+                           int* list_first, LetRecord* send, size_t send_cap, bool prune) {
     // prune = false: theta2 = 0 makes every node "openable": every private node goes to every partner (the test switch
     // that shows the pruning changes nothing but the volume)
     const float t2 = prune ? theta2 : 0.f;
-    hipLaunchKernelGGL(k_let_upper, dim3(1), dim3(kMaxRanks * kBoxes), 0, s, global_nodes, top_index, ends, edge, G, me, t2, upper_ok);
-    hipLaunchKernelGGL(k_let_open_masks, grid_for(local_cap, 256), dim3(256), 0, s, global_nodes, offsets, info, ends, G, me, t2, parent, link);
-    hipLaunchKernelGGL(k_let_flag_pack, grid_for(local_cap, kPackThreads), dim3(kPackThreads), 0, s, global_nodes, offsets, info, depth, top_index,
-                       ends, upper_ok, link, G, me, send, send_stride, let_count);
+    hipLaunchKernelGGL(k_let_upper, dim3(1), dim3(kMaxRanks * kBoxes), 0, s, top_nodes, top_index, ends, edge, G, me, t2, upper_ok);
+    hipLaunchKernelGGL(k_let_open_masks, grid_for(local_cap, 256), dim3(256), 0, s, slice, info, ends, G, me, t2, parent, link);
+    hipLaunchKernelGGL(k_let_flag_count, grid_for(local_cap, kPackThreads), dim3(kPackThreads), 0, s, offsets, info, depth, top_index, ends, upper_ok,
+                       link, G, me, node_mask, block_n);
+    hipLaunchKernelGGL(k_let_pack_scan, dim3(1), dim3(1024), 0, s, info, G, block_n, let_count, list_first);
+    launch_pack(s, local_cap, info, slice, top_nodes, offsets, top_index, depth, node_mask, block_n, list_first, G, me, send, send_cap);
 }
-void launch_scatter(hipStream_t s, const LetRecord* recv, int n, float4* global_nodes, int global_cap) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_let_scatter, grid_for(n, 256), dim3(256), 0, s, recv, n, global_nodes, global_cap);
+void launch_pack(hipStream_t s, int local_cap, const int* info, const float4* slice, const float4* top_nodes, const int* offsets, const int* top_index,
+                 const unsigned char* depth, const unsigned int* node_mask, const int* block_first, const int* list_first, int G, int me, LetRecord* send,
+                 size_t send_cap) {
+    hipLaunchKernelGGL(k_let_pack, grid_for(local_cap, kPackThreads), dim3(kPackThreads), 0, s, slice, offsets, info, depth, top_index, top_nodes,
+                       node_mask, block_first, list_first, G, me, send, send_cap);
 }
+size_t pack_blocks(int local_cap) { return size_t(grid_for(local_cap, kPackThreads).x); }
+void launch_assemble(hipStream_t s, const float4* slice, int local_cap, const LetRecord* staged, int staged_upper, const int* in_n, const int* info,
+                     const int* offsets, const int* top_index, const float4* top_nodes, int G, int me, void* layout, int* split, float4* held) {
+    HaloLayout* lay = static_cast<HaloLayout*>(layout);
+    hipLaunchKernelGGL(k_let_layout, dim3(1), dim3(64), 0, s, in_n, info, G, me, lay, split);
+    hipLaunchKernelGGL(k_let_place_own, grid_for(local_cap, 256), dim3(256), 0, s, slice, lay, held);
+    if (staged_upper > 0)
+        hipLaunchKernelGGL(k_let_place_halo, grid_for(staged_upper, 256), dim3(256), 0, s, staged, in_n, offsets, lay, G, me, held);
+    hipLaunchKernelGGL(k_let_place_top, dim3(1), dim3(64), 0, s, top_nodes, top_index, staged, in_n, offsets, lay, G, me, held);
+}
+size_t layout_bytes() { return sizeof(HaloLayout); }
 
 }  // namespace let
 }  // namespace nbody

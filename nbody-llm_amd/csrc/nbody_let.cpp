@@ -51,8 +51,18 @@ struct State {
     int* d_top_index = nullptr;   // [G][kLevels]
     int* d_split = nullptr;       // [4]: first[0] = 0, first[1] = total nodes, n_anc[0] = 0
     int local_cap = 0;            // nodes a slice can have
-    float4* d_global = nullptr;   // the global-index node array
-    int global_cap = 0;
+    float4* d_slice = nullptr;    // [local_cap] my slice of the world's node array, links local (the emit writes it)
+    float4* d_held = nullptr;     // [held_cap] the nodes this rank holds -- its slice and the imports -- in global-index order,
+    size_t held_cap = 0;          //   links = positions: what the walk runs over (launch_assemble)
+    float4* d_top_nodes = nullptr;   // [G][kLevels][2] the finished spanning cells (global links)
+    unsigned int* d_node_mask = nullptr;   // [local_cap] partners every node of the slice goes to
+    int* d_block_n = nullptr;     // [pack_blocks(local_cap)][kMaxRanks]
+    int* d_in_n = nullptr;        // [G] records received from each rank this pass
+    int* h_in_pin = nullptr;      // pinned staging of d_in_n
+    void* d_layout = nullptr;
+    int* d_zero = nullptr;        // [1] = 0: the slice is emitted with local indices
+    size_t staged = 0;            // emulation: records in the staging buffer so far
+    uint64_t send_regrown = 0;    // times the export buffer had to grow (and the lists were written again)
     int* d_order = nullptr;
     int* d_tree_info = nullptr;   // [4] of the local build
     void* d_ws = nullptr;         // workspace of the build
@@ -62,8 +72,9 @@ struct State {
     unsigned int* d_upper_ok = nullptr;   // [kLevels]
     int2* d_node_flags = nullptr;   // per node of the slice: {its parent, the partners that could open it}
     int* d_let_count = nullptr;   // [G] nodes for each partner
-    LetRecord* d_let_send = nullptr;      // [G][let_stride]
-    size_t let_stride = 0;
+    LetRecord* d_let_send = nullptr;      // [let_send_cap] the export lists, one after the other (d_list_first)
+    size_t let_send_cap = 0;
+    int* d_list_first = nullptr;          // [G + 1]
     LetRecord* d_let_recv = nullptr;
     size_t let_recv_cap = 0;
     int* d_let_matrix = nullptr;  // [G][G] counts (all-gathered rows)
@@ -90,6 +101,8 @@ struct State {
 };
 
 namespace {
+
+constexpr long long kNoClamp = 0x7fffffffLL;   // the lists travel whole (exchange_layout's clamp)
 
 int fail(NbodyHandle* h, int code, const std::string& msg) { h->err = msg; return code; }
 
@@ -152,30 +165,37 @@ int ensure_node_buffers(NbodyHandle* h, State& s) {
     const Shard& sh = h->sh;
     const int want_local = 4 * sh.seg_cap + 64;
     if (s.local_cap < want_local) {
-        for (void* p : {(void*)s.d_parent, (void*)s.d_depth, (void*)s.d_node_flags, (void*)s.d_let_send})
+        for (void* p : {(void*)s.d_parent, (void*)s.d_depth, (void*)s.d_node_flags, (void*)s.d_let_send, (void*)s.d_slice, (void*)s.d_node_mask, (void*)s.d_block_n})
             if (p) (void)hipFree(p);
-        s.d_parent = nullptr; s.d_depth = nullptr; s.d_node_flags = nullptr; s.d_let_send = nullptr;
+        s.d_parent = nullptr; s.d_depth = nullptr; s.d_node_flags = nullptr; s.d_let_send = nullptr; s.d_slice = nullptr; s.d_node_mask = nullptr; s.d_block_n = nullptr;
         int rc;
+        if ((rc = dev_alloc(h, &s.d_slice, size_t(want_local) * 2))) return rc;
+        if ((rc = dev_alloc(h, &s.d_node_mask, size_t(want_local)))) return rc;
+        if ((rc = dev_alloc(h, &s.d_block_n, pack_blocks(want_local) * size_t(kMaxRanks)))) return rc;
         if ((rc = dev_alloc(h, &s.d_parent, size_t(want_local)))) return rc;
         if ((rc = dev_alloc(h, &s.d_depth, size_t(want_local)))) return rc;
         if ((rc = dev_alloc(h, &s.d_node_flags, size_t(want_local)))) return rc;
-        s.let_stride = size_t(want_local);
-        if ((rc = dev_alloc(h, &s.d_let_send, s.let_stride * size_t(s.G)))) return rc;
-        if (s.let_recv_cap < s.let_stride) {   // room for as many imports as a slice can have nodes: no allocation inside a step
+        // exports and imports: room for a quarter of the slice's node capacity each -- the body capacity's worth of nodes, several
+        // times what the tests and the configs' sizes move (0.2-0.7 of the slice's LIVE nodes); both grow when a step needs more
+        const size_t lists = size_t(want_local) / size_t(std::max(1, tuning().let_list_div)) + 1024;
+        s.let_send_cap = lists;
+        if ((rc = dev_alloc(h, &s.d_let_send, s.let_send_cap))) return rc;
+        if (s.let_recv_cap < lists) {
             if (s.d_let_recv) (void)hipFree(s.d_let_recv);
             s.d_let_recv = nullptr; s.let_recv_cap = 0;
-            if ((rc = dev_alloc(h, &s.d_let_recv, s.let_stride))) return rc;
-            s.let_recv_cap = s.let_stride;
+            if ((rc = dev_alloc(h, &s.d_let_recv, lists))) return rc;
+            s.let_recv_cap = lists;
         }
         s.local_cap = want_local;
     }
-    const long long want_global = 4LL * (long long)h->cfg.capacity + 64LL * s.G + 64;
-    if (s.global_cap < want_global) {
-        if (s.d_global) (void)hipFree(s.d_global);
-        s.d_global = nullptr;
+    // what the walk runs over: room for the slice and for as many imports as the staging buffer takes -- a rank's own
+    // capacity decides it, not the world's size
+    if (s.held_cap < size_t(s.local_cap) + s.let_recv_cap) {
+        if (s.d_held) (void)hipFree(s.d_held);
+        s.d_held = nullptr; s.held_cap = 0;
         int rc;
-        if ((rc = dev_alloc(h, &s.d_global, size_t(want_global) * 2))) return rc;
-        s.global_cap = int(std::min<long long>(want_global, 0x7fffffff));
+        if ((rc = dev_alloc(h, &s.d_held, (size_t(s.local_cap) + s.let_recv_cap) * 2))) return rc;
+        s.held_cap = size_t(s.local_cap) + s.let_recv_cap;
     }
     if (s.ws_cap < size_t(sh.seg_cap)) {
         if (s.d_ws) (void)hipFree(s.d_ws);
@@ -207,6 +227,42 @@ int ensure_mig_recv(NbodyHandle* h, State& s, size_t need, size_t keep) {
     if (s.d_recv_mig) (void)hipFree(s.d_recv_mig);
     s.d_recv_mig = fresh;
     s.mig_recv_cap = cap;
+    return NBODY_OK;
+}
+
+// room for `need` imported node records in the staging buffer (the first `keep` survive a reallocation), and with it in
+// the array the walk runs over.  Called at points where the host is synchronised with the stream or about to be.
+int ensure_let_recv(NbodyHandle* h, State& s, size_t need, size_t keep) {
+    if (need <= s.let_recv_cap) return NBODY_OK;
+    const size_t cap = need + need / 4 + 1024;
+    LetRecord* fresh = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(LetRecord)));
+    if (keep > 0 && s.d_let_recv) HIP_TRY(h, hipMemcpyAsync(fresh, s.d_let_recv, keep * sizeof(LetRecord), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (s.d_let_recv) (void)hipFree(s.d_let_recv);
+    s.d_let_recv = fresh;
+    s.let_recv_cap = cap;
+    if (s.d_held) (void)hipFree(s.d_held);
+    s.d_held = nullptr; s.held_cap = 0;
+    int rc = dev_alloc(h, &s.d_held, (size_t(s.local_cap) + s.let_recv_cap) * 2);
+    if (rc) return rc;
+    s.held_cap = size_t(s.local_cap) + s.let_recv_cap;
+    return NBODY_OK;
+}
+
+// room for `need` records of export lists; growing means writing the lists again (launch_pack: the counts and every node's
+// partners are still on the device).  Called where the host has just read this pass's counts.
+int ensure_let_send(NbodyHandle* h, State& s, size_t need) {
+    if (need <= s.let_send_cap) return NBODY_OK;
+    if (s.d_let_send) (void)hipFree(s.d_let_send);
+    s.d_let_send = nullptr; s.let_send_cap = 0;
+    const size_t cap = need + need / 4 + 1024;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_let_send), cap * sizeof(LetRecord)));
+    s.let_send_cap = cap;
+    s.send_regrown += 1;
+    launch_pack(h->stream, s.local_cap, s.d_tree_info, s.d_slice, s.d_top_nodes, s.d_offsets, s.d_top_index, s.d_depth, s.d_node_mask, s.d_block_n,
+                s.d_list_first, s.G, s.me, s.d_let_send, s.let_send_cap);
+    HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
 
@@ -260,14 +316,15 @@ int phase3(NbodyHandle* h, State& s) {
     Shard& sh = h->sh;
     PhaseTimer timer(h, s, 3);
     HIP_TRY(h, hipMemsetAsync(s.d_let_count, 0, sizeof(int) * s.G, h->stream));
-    launch_offsets(h->stream, s.d_rb, s.G, s.global_cap, s.d_offsets, s.d_flags, s.rebalance ? s.d_bounds : s.d_bounds_scratch);
-    // my slice, straight to its place in the global-index array
-    if (tree_emit_nodes(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->width, s.d_ws, s.ws_cap, s.d_global, s.global_cap, s.local_cap,
-                        s.d_order, s.d_tree_info, 0, s.d_edge, s.d_offsets + s.me, s.d_parent, s.d_depth) != 0)
+    launch_offsets(h->stream, s.d_rb, s.G, s.d_offsets, s.d_flags, s.rebalance ? s.d_bounds : s.d_bounds_scratch);
+    // my slice of the world's node array, with local indices and links (the wire and the assembly shift them)
+    if (tree_emit_nodes(h->stream, sh.own_pos(), sh.own_count(), int(h->n_local), h->width, s.d_ws, s.ws_cap, s.d_slice, s.local_cap, s.local_cap,
+                        s.d_order, s.d_tree_info, 0, s.d_edge, s.d_zero, s.d_parent, s.d_depth) != 0)
         return fail(h, NBODY_ERR_HIP, "device octree build failed");
-    launch_finalize(h->stream, s.d_rb, s.d_ends, s.G, s.me, h->width, s.d_global, s.global_cap, s.d_offsets, s.d_top_index);
-    launch_flags_and_pack(h->stream, s.local_cap, s.d_tree_info, s.d_edge, s.d_global, s.d_offsets, s.d_top_index, s.d_ends, s.G, s.me, h->theta2,
-                          s.d_parent, s.d_depth, s.d_upper_ok, s.d_node_flags, s.d_let_count, s.d_let_send, s.let_stride, s.prune);
+    launch_finalize(h->stream, s.d_rb, s.d_ends, s.G, s.me, h->width, s.d_slice, s.d_offsets, s.d_top_index, s.d_top_nodes);
+    launch_flags_and_pack(h->stream, s.local_cap, s.d_tree_info, s.d_edge, s.d_slice, s.d_top_nodes, s.d_offsets, s.d_top_index, s.d_ends, s.G, s.me,
+                          h->theta2, s.d_parent, s.d_depth, s.d_upper_ok, s.d_node_flags, s.d_node_mask, s.d_block_n, s.d_let_count, s.d_list_first,
+                          s.d_let_send, s.let_send_cap, s.prune);
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
 }
@@ -276,11 +333,16 @@ int phase3(NbodyHandle* h, State& s) {
 int phase4(NbodyHandle* h, State& s, float dt, bool kick) {
     Shard& sh = h->sh;
     PhaseTimer timer(h, s, 4);
-    // first[] of the unsplit walk: {0, total}; the total lives on the device (offsets[G])
-    HIP_TRY(h, hipMemsetAsync(s.d_split, 0, 4 * sizeof(int), h->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.d_split + 1, s.d_offsets + s.G, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    // the nodes this rank holds, in global-index order, links = positions; first[] of the unsplit walk = {0, nodes held}
+    {
+        size_t staged_upper = 0;
+        for (int r = 0; r < s.G; ++r) { s.h_in_pin[r] = s.recv_n[r]; staged_upper += size_t(std::max(0, s.recv_n[r])); }
+        HIP_TRY(h, hipMemcpyAsync(s.d_in_n, s.h_in_pin, sizeof(int) * size_t(s.G), hipMemcpyHostToDevice, h->stream));
+        launch_assemble(h->stream, s.d_slice, s.local_cap, s.d_let_recv, int(staged_upper), s.d_in_n, s.d_tree_info, s.d_offsets, s.d_top_index,
+                        s.d_top_nodes, s.G, s.me, s.d_layout, s.d_split, s.d_held);
+    }
     TreeDev td;
-    td.nodes = s.d_global; td.n_nodes = s.global_cap;
+    td.nodes = s.d_held; td.n_nodes = int(std::min<size_t>(s.held_cap, 0x7fffffff));
     td.order = s.d_order; td.n_order = int(h->n_local);
     td.n_order_dev = sh.own_count();
     td.poison = s.d_flags;
@@ -347,6 +409,12 @@ int create(NbodyHandle* h) {
     HIP_TRY(h, hipHostMalloc(&s.h_pin, (size_t(report_ints(s.G)) + 64) * sizeof(int), hipHostMallocDefault));
     if ((rc = dev_alloc(h, &s.d_report, size_t(report_ints(s.G))))) return rc;
     if ((rc = dev_alloc(h, &s.d_pred, size_t(s.G) * s.G))) return rc;
+    if ((rc = dev_alloc(h, &s.d_top_nodes, size_t(s.G) * kLevels * 2))) return rc;
+    if ((rc = dev_alloc(h, &s.d_list_first, size_t(s.G) + 1))) return rc;
+    if ((rc = dev_alloc(h, &s.d_in_n, size_t(s.G)))) return rc;
+    if ((rc = dev_alloc(h, &s.d_zero, 1))) return rc;
+    if ((rc = dev_alloc(h, reinterpret_cast<char**>(&s.d_layout), layout_bytes()))) return rc;
+    HIP_TRY(h, hipHostMalloc(&s.h_in_pin, size_t(s.G) * sizeof(int), hipHostMallocDefault));
     HIP_TRY(h, hipHostMalloc(&s.h_pred_pin, size_t(s.G) * s.G * sizeof(int), hipHostMallocDefault));
     s.h_pred.assign(size_t(s.G) * s.G, 0);
     h->sh.poison = s.d_flags;   // a raised flag stops every kernel that would change the state
@@ -358,7 +426,8 @@ void destroy(NbodyHandle* h) {
     State* s = h->let;
     if (!s) return;
     void* dev[] = {s->d_bounds, s->d_bounds_scratch, s->d_weight_sum, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_send_off, s->d_mig_cursor, s->d_mig_matrix, s->d_dest_of, s->d_new_count, s->d_flags, s->d_box_ord,
-                   s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_global, s->d_order, s->d_tree_info,
+                   s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_slice, s->d_held, s->d_top_nodes, s->d_node_mask,
+                   s->d_block_n, s->d_in_n, s->d_layout, s->d_zero, s->d_list_first, s->d_order, s->d_tree_info,
                    s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_send,
                    s->d_let_recv, s->d_let_matrix, h->sh.ids, s->d_report, s->d_pred, s->d_slot_out};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -366,6 +435,7 @@ void destroy(NbodyHandle* h) {
     h->sh.poison = nullptr;
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     if (s->h_pred_pin) (void)hipHostFree(s->h_pred_pin);
+    if (s->h_in_pin) (void)hipHostFree(s->h_in_pin);
     if (s->ev_made) for (auto& set : s->ev) for (hipEvent_t e : set) (void)hipEventDestroy(e);
     delete s;
     h->let = nullptr;
@@ -648,7 +718,8 @@ int stats(NbodyHandle* h, NbodyLetStats* out) {
     s.st.host_syncs = s.host_syncs;
     s.st.migrant_respills = s.spills;
     s.st.node_array_peak_bytes = s.node_array_peak * sizeof(LetRecord);
-    s.st.node_array_bytes = uint64_t(std::max(0, s.global_cap)) * sizeof(LetRecord);
+    // every buffer of node records this rank has: its slice, the array the walk runs over, the export lists, the staged imports
+    s.st.node_array_bytes = uint64_t(s.held_cap + size_t(std::max(0, s.local_cap)) + s.let_send_cap + s.let_recv_cap) * sizeof(LetRecord);
     *out = s.st;
     return NBODY_OK;
 }
@@ -673,8 +744,8 @@ static void account_from(NbodyHandle* h, State& s, const int* rep) {
     if (h->comm_ready)
         for (int r = 0; r < G; ++r) {
             if (r == s.me) continue;
-            sent += uint64_t(std::min<long long>(std::max(0, let_m[s.me * G + r]), (long long)s.let_stride));
-            rec += uint64_t(std::min<long long>(std::max(0, let_m[r * G + s.me]), (long long)s.let_stride));
+            sent += uint64_t(std::max(0, let_m[s.me * G + r]));
+            rec += uint64_t(std::max(0, let_m[r * G + s.me]));
         }
     s.st.nodes_sent += sent;
     s.st.nodes_received += rec;
@@ -876,24 +947,21 @@ static int pass(NbodyHandle* h, float dt, bool is_step) {
     account_from(h, s, rep);
     std::fill(s.recv_n.begin(), s.recv_n.end(), 0);
     if (comm) {
-        for (int a = 0; a < G; ++a)
-            for (int b = 0; b < G; ++b)
-                if (a != b && size_t(std::max(0, rep[a * G + b])) > s.let_stride)   // (every rank sees the same matrix: all of them stop here)
-                    return fail(h, NBODY_ERR_CAPACITY, "spatial shards: export list overflow (rank " + std::to_string(a) + " has " + std::to_string(rep[a * G + b]) +
-                                                           " nodes for rank " + std::to_string(b) + ", its list holds " + std::to_string(s.let_stride) + ")");
-        const size_t total_in = exchange_layout(rep, G, s.me, (long long)s.let_stride, false, s.let_stride, out_at, n_out, in_at, n_in);
-        for (int r = 0; r < G; ++r) s.recv_n[r] = int(n_in[r]);
-        if (total_in > s.let_recv_cap) {   // (sized for a slice's worth at creation: only a rank that imports more than it can own gets here)
-            if (s.d_let_recv) (void)hipFree(s.d_let_recv);
-            s.d_let_recv = nullptr; s.let_recv_cap = 0;
-            HIP_TRY(h, hipMalloc(&s.d_let_recv, (total_in + total_in / 4 + 1024) * sizeof(LetRecord)));
-            s.let_recv_cap = total_in + total_in / 4 + 1024;
+        const size_t total_in = exchange_layout(rep, G, s.me, kNoClamp, true, 0, out_at, n_out, in_at, n_in);
+        {   // my lists lie one after the other; a buffer that was too small for them is grown and written again (the counts
+            // and every node's partners are still on the device: only the last kernel of the export runs twice)
+            size_t total_out = 0;
+            for (int r = 0; r < G; ++r) total_out += n_out[r];
+            rc = ensure_let_send(h, s, total_out);
+            if (rc) return rc;
         }
+        for (int r = 0; r < G; ++r) s.recv_n[r] = int(n_in[r]);
+        rc = ensure_let_recv(h, s, total_in, 0);   // (sized for a slice's worth at creation: only a rank that imports more than it can own grows it)
+        if (rc) return rc;
         rc = draw_prediction(h, s, rep + gg);   // (before h_pin is reused; uploads next step's sizes)
         if (rc) return rc;
         rc = variable_round(h, s, reinterpret_cast<const char*>(s.d_let_send), reinterpret_cast<char*>(s.d_let_recv), sizeof(LetRecord), out_at, n_out, in_at, n_in);
         if (rc) return rc;
-        if (total_in > 0) launch_scatter(h->stream, s.d_let_recv, int(total_in), s.d_global, s.global_cap);
     }
     rc = phase4(h, s, dt, is_step);
     if (rc) return rc;
@@ -914,7 +982,15 @@ int debug_phase(NbodyHandle* h, int phase, float dt) {
         case 10: return phase0(h, s, dt, false);   // the same for a force pass outside a step (no drift)
         case 1: return phase1(h, s);
         case 2: return phase2(h, s);
-        case 3: { std::fill(s.recv_n.begin(), s.recv_n.end(), 0); return phase3(h, s); }
+        case 3: {
+            std::fill(s.recv_n.begin(), s.recv_n.end(), 0);
+            s.staged = 0;
+            int rc = phase3(h, s);
+            if (rc) return rc;
+            HIP_TRY(h, hipMemcpyAsync(s.h_pin, s.d_list_first + s.G, sizeof(int), hipMemcpyDeviceToHost, h->stream));   // all my lists together
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            return ensure_let_send(h, s, size_t(std::max(0, s.h_pin[0])));
+        }
         case 4: { int rc = phase4(h, s, dt, true); if (rc) return rc; rc = account(h, s); return rc ? rc : check_flags(h); }
         case 14: { int rc = phase4(h, s, dt, false); if (rc) return rc; rc = account(h, s); return rc ? rc : check_flags(h); }
         default: return fail(h, NBODY_ERR_INVALID, "unknown phase");
@@ -949,18 +1025,18 @@ int debug_exchange(NbodyHandle* h, NbodyHandle* peer, int which) {
         case 3: {
             int n = 0;
             HIP_TRY(h, hipMemcpy(&n, p.d_let_count + me, sizeof(int), hipMemcpyDeviceToHost));
-            if (size_t(n) > p.let_stride) return fail(h, NBODY_ERR_CAPACITY, "export list overflow");
-            if (size_t(n) > s.let_recv_cap) {
-                HIP_TRY(h, hipStreamSynchronize(h->stream));
-                if (s.d_let_recv) (void)hipFree(s.d_let_recv);
-                s.d_let_recv = nullptr; s.let_recv_cap = 0;
-                HIP_TRY(h, hipMalloc(&s.d_let_recv, (size_t(n) + size_t(n) / 4 + 1024) * sizeof(LetRecord)));
-                s.let_recv_cap = size_t(n) + size_t(n) / 4 + 1024;
+            int first = 0;
+            HIP_TRY(h, hipMemcpy(&first, p.d_list_first + me, sizeof(int), hipMemcpyDeviceToHost));
+            if (size_t(first) + size_t(n) > p.let_send_cap) return fail(h, NBODY_ERR_CAPACITY, "emulation: the peer's export lists were not written whole");
+            for (int r = pr; r < s.G; ++r)
+                if (r != me && s.recv_n[r] != 0) return fail(h, NBODY_ERR_INVALID, "emulation: the node lists must arrive in rank order");
+            {
+                int rc = ensure_let_recv(h, s, s.staged + size_t(n), s.staged);
+                if (rc) return rc;
             }
-            if (n > 0) {
-                HIP_TRY(h, hipMemcpyAsync(s.d_let_recv, p.d_let_send + size_t(me) * p.let_stride, size_t(n) * sizeof(LetRecord), hipMemcpyDeviceToDevice, h->stream));
-                launch_scatter(h->stream, s.d_let_recv, n, s.d_global, s.global_cap);
-            }
+            if (n > 0)
+                HIP_TRY(h, hipMemcpyAsync(s.d_let_recv + s.staged, p.d_let_send + size_t(first), size_t(n) * sizeof(LetRecord), hipMemcpyDeviceToDevice, h->stream));
+            s.staged += size_t(n);
             s.recv_n[pr] = n;
             break;
         }

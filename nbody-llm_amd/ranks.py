@@ -9,7 +9,7 @@ flow -- count matrices, variable-size rounds, stream ordering, host synchronisat
 RCCL refuses to put two ranks on one device.  With "rccl", rank r uses device r (one process per GPU).
 
 cfg (JSON): world, address (socket path), out (directory), transport, device (ipc: the shared device),
-  sim {method bf|bh, math fast|strict, shard index|spatial, tree auto|host|device, leaf reference|direct},
+  sim {method bf|bh, math fast|strict, shard index|spatial, tree auto|host|device, leaf reference|direct, tuning {knob: value}},
   ics {kind plummer|disc, n, seed, mass_jitter (seed or null)}, box [[cx, cy, cz], width], settings {g, g_soft, dt, theta2},
   schedule [["steps", k] | ["step_by", dt] | ["update_forces"] | ["settings", {...}] | ["sync"]], env {NAME: value},
   env_by_rank {"r": {NAME: value}}.
@@ -62,7 +62,8 @@ def make_sim(nb, cfg: dict, points: np.ndarray, rank: int, world: int, device: i
         capacity=int(sim_cfg.get("capacity", len(points))), device=device, rank=rank, world_size=world,
         tree_build={"auto": nb.TREE_AUTO, "host": nb.TREE_HOST, "device": nb.TREE_DEVICE}[sim_cfg.get("tree", "auto")],
         leaf_mode=nb.LEAF_DIRECT if sim_cfg.get("leaf", "reference") == "direct" else nb.LEAF_REFERENCE,
-        shard_mode=nb.SHARD_SPATIAL if sim_cfg.get("shard", "index") == "spatial" else nb.SHARD_INDEX)
+        shard_mode=nb.SHARD_SPATIAL if sim_cfg.get("shard", "index") == "spatial" else nb.SHARD_INDEX,
+        tuning=sim_cfg.get("tuning"))
 
 
 def run_schedule(nb, sim, schedule, reattach=None):

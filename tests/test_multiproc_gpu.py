@@ -153,6 +153,28 @@ def test_barnes_hut_spatial_ranks_with_migration(gpu, tmp_path, G, n, box_w, lea
             assert 0 < r["let"]["node_array_peak_bytes"] <= r["let"]["node_array_bytes"]
 
 
+def test_spatial_ranks_grow_their_node_list_buffers_inside_a_step(gpu, tmp_path):
+    """The export lists lie one after the other in a buffer sized for a quarter of the slice's node capacity, the imports
+    are staged in one of the same size; a step that needs more grows them where the host has just read the counts (the
+    export lists are then written again).  With buffers of ~1 000 records every step of this world does: same bodies, to
+    the bit, as with the default sizes."""
+    from nbody_llm_amd import ranks
+    box = [[0.0, 0.0, 0.0], 3.0]
+    sd = dict(g=1.0, g_soft=0.01, dt=5e-3, theta2=0.25)
+    runs = []
+    for k, tuning in enumerate((None, {"let_list_div": 1 << 20})):
+        sim = dict(method="bh", math="fast", shard="spatial")
+        if tuning:
+            sim["tuning"] = tuning
+        cfg = world_cfg(tmp_path / f"run{k}", 4, sim, dict(n=20000, seed=64), sd, [["steps", 4]], box=box)
+        runs.append(launch(cfg, 4))
+    a, b = (ranks.gather_world(r) for r in runs)
+    assert len(a) == len(b) and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    for ra, rb in zip(*runs):
+        assert ra["let"]["nodes_received"] == rb["let"]["nodes_received"] > 4 * 2048   # (more than the small buffers held at first)
+        assert rb["let"]["node_array_bytes"] < ra["let"]["node_array_bytes"]
+
+
 def test_spatial_step_repeats_its_migrant_round_when_the_posted_sizes_do_not_hold(gpu, tmp_path):
     """The migrant messages of a step are posted with sizes drawn from the previous step's counts.  Two quiet steps, then
     one that moves every body a long way: far more bodies change ranks than predicted, every rank sees it in the

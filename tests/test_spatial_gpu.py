@@ -2,7 +2,7 @@
 on ONE GPU: G handles of this process play ranks 0..G-1; the four exchanges a step makes with RCCL are done with
 device-to-device copies (nbody_debug_let_*).  Everything else is the production code: ownership by Morton-key range,
 migration, the distributed device build, the spanning cells, the export pruned by the partners' bounding boxes, the walk
-over the assembled global-index array.  Oracle = the single-shard device-tree run (and through it the CPU oracle)."""
+over the array of the nodes a rank holds (its slice and the imports, in global-index order).  Oracle = the single-shard device-tree run (and through it the CPU oracle)."""
 import numpy as np
 import pytest
 
@@ -254,6 +254,32 @@ def test_pruning_changes_the_volume_not_the_result(gpu):
     sent_pruned = sum(l.nodes_sent for l in b[3])
     assert 0 < sent_pruned < 0.6 * sent_all
     print(f"nodes exported over 3 steps, 4 ranks: unpruned {sent_all}, pruned {sent_pruned} ({sent_pruned / sent_all:.1%})")
+
+
+def test_node_list_buffers_grow_when_a_step_needs_more(gpu):
+    """The export lists (one after the other in one buffer) and the staged imports start at a quarter of the slice's node
+    capacity and grow on demand -- the export lists are then written again from the per-node partner masks.  With ~1 000
+    records to start with every step grows something: the bits do not change, and with pruning off (every node to every
+    partner: the largest lists there are) neither."""
+    nb = gpu
+    n, G = 20000, 4
+    st = nb.Settings(1.0, 0.01, 1e-3, 0.25)
+    ics = nb.plummer(n, seed=63)
+    for prune in (True, False):
+        out = []
+        for tuning in (None, {"let_list_div": 1 << 20}):
+            sims = make_world(nb, ics, G, BOX, st, prune=prune, tuning=tuning)
+            for _ in range(3):
+                nb.spatial_step(sims)
+            rec, idx = nb.spatial_gather(sims, n)
+            out.append((rec, idx, [s.let_stats() for s in sims]))
+            close(sims)
+        a, b = out
+        assert np.array_equal(a[1], b[1])
+        for f in FIELDS:
+            assert np.array_equal(a[0][f].view(np.uint32), b[0][f].view(np.uint32)), (prune, f)
+        assert [l.nodes_received for l in a[2]] == [l.nodes_received for l in b[2]]
+        assert min(l.nodes_received for l in b[2]) > 3 * 2048    # (more per step than the small buffers held at first)
 
 
 @pytest.mark.parametrize("G,n,box_w", [(2, 3000, 64.0), (4, 20000, 64.0), (3, 9000, 2.5), (8, 20000, 3.0)])
