@@ -246,7 +246,9 @@ typedef struct NbodyLetStats {
     uint64_t host_syncs;        /* host synchronisations inside the passes (steady state: one per pass, where the export counts are read) */
     uint64_t migrant_respills;  /* passes whose migrants did not fit the sizes their messages were posted with and made the round twice */
     uint64_t node_array_peak_bytes;  /* most bytes of node records this rank held at once: its own slice + what it imported */
-    uint64_t node_array_bytes;       /* bytes of the global-index array those records are scattered over (address range, sparsely written) */
+    uint64_t node_array_bytes;       /* bytes of every buffer of node records this rank has allocated: its slice, the array the walk runs over
+                                        (slice + imports, in global-index order), the export lists, the staged imports -- sized from the
+                                        rank's own capacity, not from the world's */
 } NbodyLetStats;
 int nbody_let_stats(NbodyHandle* h, NbodyLetStats* out);
 

@@ -527,42 +527,33 @@ __global__ __launch_bounds__(kPackThreads) void k_let_flag_count(const int* __re
 }
 // block_n[b][r] -> the first slot of block b in list r (exclusive scan over the blocks, one partner after the other);
 // let_count[r] = the list's length
-// list_first[r] = where list r starts in the send buffer (the lists lie one after the other, each exactly as long as it is)
-__global__ __launch_bounds__(1024) void k_let_pack_scan(const int* __restrict__ info, int G, int* __restrict__ block_n, int* __restrict__ let_count,
-                                                        int* __restrict__ list_first /* [G + 1] */) {
-    __shared__ int part[1024][kMaxRanks];              // 64 KB: the threads' sums, all partners at once
+// list_first[r] = where list r starts in the send buffer (the lists lie one after the other, each exactly as long as it is).
+// One wave per partner (kMaxRanks waves): its lanes take consecutive runs of blocks, a wave scan joins them -- no barrier
+// until the lists' first slots are added up at the end.
+__global__ __launch_bounds__(64 * kMaxRanks) void k_let_pack_scan(const int* __restrict__ info, int G, int* __restrict__ block_n, int* __restrict__ let_count,
+                                                                  int* __restrict__ list_first /* [G + 1] */) {
+    __shared__ int total[kMaxRanks];
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_blocks = (info[0] + kPackThreads - 1) / kPackThreads;
-    const int per = (n_blocks + 1023) / 1024;          // consecutive blocks per thread
-    const int b0 = threadIdx.x * per, b1 = min(n_blocks, b0 + per);
-    int sum[kMaxRanks];
+    const int per = (n_blocks + 63) / 64;              // consecutive blocks per lane
+    const int b0 = lane * per, b1 = min(n_blocks, b0 + per);
+    int sum = 0;
+    if (r < G) for (int b = b0; b < b1; ++b) sum += block_n[b * kMaxRanks + r];
+    int incl = sum;                                     // inclusive scan over the wave's lanes
 #pragma unroll
-    for (int r = 0; r < kMaxRanks; ++r) sum[r] = 0;
-    for (int b = b0; b < b1; ++b)
-#pragma unroll
-        for (int r = 0; r < kMaxRanks; ++r) if (r < G) sum[r] += block_n[b * kMaxRanks + r];
-#pragma unroll
-    for (int r = 0; r < kMaxRanks; ++r) part[threadIdx.x][r] = sum[r];
-    __syncthreads();
-    for (int step = 1; step < 1024; step <<= 1) {      // inclusive scan over the threads
-        int v[kMaxRanks];
-#pragma unroll
-        for (int r = 0; r < kMaxRanks; ++r) v[r] = (int(threadIdx.x) >= step) ? part[threadIdx.x - step][r] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kMaxRanks; ++r) part[threadIdx.x][r] += v[r];
-        __syncthreads();
+    for (int step = 1; step < 64; step <<= 1) {
+        const int v = __shfl_up(incl, step);
+        if (lane >= step) incl += v;
     }
-#pragma unroll
-    for (int r = 0; r < kMaxRanks; ++r) {
-        if (r >= G) continue;
-        int run = part[threadIdx.x][r] - sum[r];
+    if (r < G) {
+        int run = incl - sum;
         for (int b = b0; b < b1; ++b) { const int c = block_n[b * kMaxRanks + r]; block_n[b * kMaxRanks + r] = run; run += c; }
-        if (threadIdx.x == 1023) let_count[r] = part[1023][r];
+        if (lane == 63) { let_count[r] = incl; total[r] = incl; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         long long run = 0;
-        for (int r = 0; r < G; ++r) { list_first[r] = int(min(run, 0x7fffffffLL)); run += part[1023][r]; }
+        for (int q = 0; q < G; ++q) { list_first[q] = int(min(run, 0x7fffffffLL)); run += total[q]; }
         list_first[G] = int(min(run, 0x7fffffffLL));
     }
 }
@@ -748,7 +739,7 @@ void launch_flags_and_pack(hipStream_t s, int local_cap, const int* info, const 
     hipLaunchKernelGGL(k_let_open_masks, grid_for(local_cap, 256), dim3(256), 0, s, slice, info, ends, G, me, t2, parent, link);
     hipLaunchKernelGGL(k_let_flag_count, grid_for(local_cap, kPackThreads), dim3(kPackThreads), 0, s, offsets, info, depth, top_index, ends, upper_ok,
                        link, G, me, node_mask, block_n);
-    hipLaunchKernelGGL(k_let_pack_scan, dim3(1), dim3(1024), 0, s, info, G, block_n, let_count, list_first);
+    hipLaunchKernelGGL(k_let_pack_scan, dim3(1), dim3(64 * kMaxRanks), 0, s, info, G, block_n, let_count, list_first);
     launch_pack(s, local_cap, info, slice, top_nodes, offsets, top_index, depth, node_mask, block_n, list_first, G, me, send, send_cap);
 }
 void launch_pack(hipStream_t s, int local_cap, const int* info, const float4* slice, const float4* top_nodes, const int* offsets, const int* top_index,

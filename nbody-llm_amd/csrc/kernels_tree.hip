@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_tree_keys(const P4* __restrict__ pos, c
                                                    unsigned long long* __restrict__ keys, int* __restrict__ ids,
                                                    int* __restrict__ out_info, int* __restrict__ counters) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k == 0) { out_info[0] = 0; out_info[1] = 0; counters[0] = 0; counters[1] = 0; }  // node count and flags of this build; k_tree_ties' list length and finished blocks (first kernel of the build)
+    if (k == 0) { out_info[0] = 0; out_info[1] = 0; counters[0] = 0; }  // node count and flags of this build; k_tree_ties' list length (first kernel of the build)
     if (k >= n_upper) return;
     if (k >= *count) {  // n_upper only bounds the live count: the unused tail sorts to the end (bit 63 set),
         keys[k] = ~0ull;  // where every later kernel ignores it (they all read *count)
@@ -110,7 +110,7 @@ __device__ __forceinline__ int common_levels2(const unsigned long long* __restri
 // (insertion sort; the radix sort is stable, so equal keys keep ascending ids), and inside it every run of equal FULL
 // keys gets its second keys (levels 21..41) and is put in their order.  Groups are pairs in practice.  A group of more
 // than kMaxLowGroup bodies (a dense clump inside one level-16 cell, 1e-3 of a width-64 box) is not sorted by one thread:
-// its bounds go on a list and the last workgroup of k_tree_ties sorts it (sort_big_groups: up to kMaxBigGroup bodies,
+// its bounds go on a list and k_tree_big_groups sorts it (sort_big_groups: up to kMaxBigGroup bodies,
 // kMaxBigGroups groups per build).  Beyond that -- and for a run of more than tuning().tree_max_tie (64) equal FULL keys -- the build
 // raises a flag: 1 = "deeper than the build's 42 levels", 4 = "a clump larger than the build sorts" (the single-GPU step
 // then builds on the host; a spatial rank reports it as what it is).
@@ -142,8 +142,8 @@ __device__ void finish_equal_key_runs(const P4* __restrict__ pos, Real cx0, Real
     }
 }
 
-// the listed groups (257 .. 4096 bodies sharing 16 levels), one after the other by ONE workgroup -- the last one of
-// k_tree_ties to finish (no launch of its own: the list is empty in all but pathological worlds): a stable block radix
+// the listed groups (257 .. 4096 bodies sharing 16 levels), one after the other by ONE workgroup (k_tree_big_groups; the
+// list is empty in all but pathological worlds): a stable block radix
 // sort on the 15 low key bits (the group's top bits are equal), then the runs of equal full keys as above
 template <class P4, class Real>
 __device__ void sort_big_groups(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width, unsigned long long* __restrict__ keys,
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, c
                                                    Real cz0, Real width, unsigned long long* __restrict__ keys,
                                                    unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
                                                    int kMaxTie, int* __restrict__ big_list /* {begin, end} pairs */,
-                                                   int* __restrict__ counters /* [0] pairs listed, [1] workgroups finished */) {
+                                                   int* __restrict__ counters /* [0] pairs listed */) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
     bool leader = j + 1 < n;
@@ -209,19 +209,18 @@ __global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, c
             finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, j, e, flags, kMaxTie);
         }
     }
-    // the last workgroup to get here sorts the listed groups (every other one has published its entries by then)
-    __shared__ int n_big;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int done = atomicAdd(&counters[1], 1);
-        n_big = (done == int(gridDim.x) - 1) ? min(atomicAdd(&counters[0], 0), kMaxBigGroups) : 0;
-    }
-    __syncthreads();
-    if (n_big > 0) {
-        __threadfence();
-        sort_big_groups(pos, cx0, cy0, cz0, width, keys, keys2, ids, flags, kMaxTie, big_list, n_big);
-    }
+}
+
+// The listed groups, by one workgroup in a launch of its own.  (Round 3 first let the LAST workgroup of k_tree_ties do it --
+// "last one in" needs a device-scope fence in every workgroup, and with the sort's 50 KB of LDS in the kernel that made
+// k_tree_ties 17 us instead of 4.7 at 65 536 bodies and 1 ms at 4 M: a 4.7 us launch is the cheaper way to wait for a grid.)
+template <class P4, class Real>
+__global__ __launch_bounds__(256) void k_tree_big_groups(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width,
+                                                         unsigned long long* __restrict__ keys, unsigned long long* __restrict__ keys2,
+                                                         int* __restrict__ ids, int* __restrict__ flags, int kMaxTie,
+                                                         const int* __restrict__ big_list, const int* __restrict__ counters) {
+    const int n_big = min(counters[0], kMaxBigGroups);
+    if (n_big > 0) sort_big_groups(pos, cx0, cy0, cz0, width, keys, keys2, ids, flags, kMaxTie, big_list, n_big);
 }
 
 // One thread per NODE (not per body: the first body of a big cell opens every level above it, and 15
@@ -585,7 +584,7 @@ struct BuildLayout {
     int *ids_in, *ids, *emit_count, *base, *wpre;
     signed char* delta;
     Sum4 *sums, *incl;
-    int* counters;   // [2] k_tree_ties: groups listed for the workgroup sort, workgroups finished (cleared by k_tree_keys)
+    int* counters;   // [1] k_tree_ties: groups listed for the workgroup sort (cleared by k_tree_keys)
 };
 BuildLayout build_layout(void* workspace, size_t n_cap) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -627,6 +626,8 @@ int sort_keys_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, c
     int* big_list = static_cast<int*>(L.tmp);   // (the sort is done with its scratch; the scans take it over after this)
     hipLaunchKernelGGL((k_tree_ties<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width,
                        L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie), big_list, L.counters);
+    hipLaunchKernelGGL((k_tree_big_groups<P4, Real>), dim3(1), dim3(256), 0, s, pos, center[0], center[1], center[2], width, L.keys, L.keys2, L.ids,
+                       out_info + 1, std::max(1, tuning().tree_max_tie), big_list, L.counters);
     return 0;
 }
 template <class P4>

@@ -2,18 +2,23 @@
 // the scheme.  A spatial handle is a SINGLE-segment shard (its own bodies only): drift, retain, the device build's
 // kernels and the walk run on it as on a one-GPU handle; what is added are five phases separated by four exchanges:
 //   phase 0  drift, retain, pick the bodies whose key left the rank's range and pack them per destination
-//   --- exchange 0: migrants, variable size (the G x G counts travel first: all-gather + a host synchronisation)
+//   --- exchange 0: migrants, variable size, posted with sizes drawn from the last step's counts (the G x G counts travel
+//       with them; a step whose migrants do not fit repeats the round exactly: see pass())
 //   phase 1  take the immigrants in, keys + sort of the own bodies, first/last key, boxes and weight of the own bodies
 //   --- exchange 1: all-gather of the end infos (1.6 KB per rank)
 //   phase 2  edge values, delta and the scans of the own slice, contributions to every earlier rank's spanning cells, the
 //            keys of the world's quantiles that lie on this rank (next step's bounds)
 //   --- exchange 2: all-gather of those tables (13 KB per rank)
-//   phase 3  next step's bounds, own slice emitted into the global-index array, all spanning cells finished, the nodes
-//            each partner can reach flagged (ancestors against the boxes its bodies lie in) and packed
-//   --- exchange 3: node records, variable size (counts first: all-gather + the second host synchronisation of a step)
-//   phase 4  imports dropped at their global indices, walk, kick + half drift
-// Production (`step`) does the exchanges with RCCL on the handle's stream; the tests run G handles of one process on one
-// GPU and do them as device-to-device copies (debug_phase / debug_exchange) -- same kernels, same buffers.
+//   phase 3  next step's bounds, own slice emitted (local indices), all spanning cells finished, the nodes each partner
+//            can reach flagged (ancestors against the boxes its bodies lie in) and written, in node order, into one list
+//            per partner
+//   --- exchange 3: node records, variable size (counts first: all-gather + the ONE host synchronisation of a step)
+//   phase 4  the nodes this rank holds -- its slice and the imports -- laid out in global-index order with their links
+//            turned into positions (launch_assemble), walk, kick + half drift
+// No buffer here is sized by the world: the slice, the array the walk runs over, the export lists and the staged imports
+// follow the rank's own capacity (the last two grow when a step needs more).
+// Production (`step`) does the exchanges through the handle's transport on its stream; the tests also run G handles of one
+// process on one GPU and do them as device-to-device copies (debug_phase / debug_exchange) -- same kernels, same buffers.
 #include "nbody_let.h"
 #include "kernels_let.h"
 

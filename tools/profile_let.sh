@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the spatial-shard emulation (tools/let_report.py): per-kernel times of the five phases.
-#   gpurun --timeout 600 -- 'bash tools/profile_let.sh r02 4194304'
+#   gpurun --timeout 600 -- 'bash tools/profile_let.sh r03 4194304'
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 N=${2:-4194304}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
