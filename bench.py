@@ -83,6 +83,8 @@ def parse():
                     help="--workload bh: octree build on the host (north_star, bit-exact) or on the device (SURVEY F3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bh", action="store_true", help="default line without the configs[2] object")
+    ap.add_argument("--profile-every", type=int, default=4, help="HIP events around every k-th launch of the dominant kernel (an event pair "
+                    "costs the stream ~11 us: bracketing every launch makes the steps it measures 1.5-3 %% longer)")
     ap.add_argument("--spatial-n", type=int, default=1 << 22, help="N > 1 GPUs: bodies of the configs[4] object (0: leave it out)")
     ap.add_argument("--spatial-steps", type=int, default=10)
     ap.add_argument("--spatial-timeout", type=float, default=300.0, help="seconds before the configs[3]/configs[4] objects are given up")
@@ -249,7 +251,7 @@ def run(nb, args, workload, tree, ics, box, st, rank, world, local_rank, rdzv, i
     if preheat > 0:
         sim.steps(preheat)
     sim.steps(args.warmup)
-    sim.set_profiling(True)
+    sim.set_profiling(max(1, args.profile_every))
     sim.reset_stats()
     barrier()
     t0 = time.perf_counter()
@@ -274,7 +276,7 @@ def run_spatial(nb, args, box, st, rank, world, local_rank, rdzv, ident_fn):
     sim.comm_init(ident_fn())
     sim.init()
     sim.steps(2)
-    sim.set_profiling(True)
+    sim.set_profiling(max(1, args.profile_every))
     sim.reset_stats()
     sim.sync()
     rdzv.barrier()
@@ -308,7 +310,7 @@ def bh_record(args, n, tree, elapsed, stats):
             "tree_copy": stats.tree_copy_ms / args.steps,       # host build only: D2H positions + H2D nodes (incl. waiting for the previous step)
             "walk_kernel": stats.force_kernel_ms / max(1.0, launches),
         },
-        "roofline": bh_roofline(n, stats.force_kernel_ms, launches, visits / max(1.0, launches), tree),
+        "roofline": bh_roofline(n, stats.force_kernel_ms, launches, visits / max(1, args.steps), tree),   # (one walk launch per step)
         "parity": PARITY[("bh", args.math)],
     }
     return rec
@@ -407,7 +409,7 @@ def main():
         if args.workload == "bf":
             roofline = bf_roofline(args, world, n, kernel_ms, launches, k_inter)
         else:
-            roofline = bh_roofline(n / world, kernel_ms, launches, (visits / world) / max(1.0, launches), args.tree)
+            roofline = bh_roofline(n / world, kernel_ms, launches, (visits / world) / max(1, args.steps), args.tree)
         result = {
             "metric": "pairwise_interactions_per_sec", "value": value, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

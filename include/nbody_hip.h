@@ -181,7 +181,8 @@ int nbody_elapsed_f64(const NbodyHandle* h, double* out);
 int nbody_sync(NbodyHandle* h);
 
 /* ---- diagnostics (no reference counterpart) -------------------------------------------------- */
-int nbody_set_profiling(NbodyHandle* h, int on); /* HIP events around every force-kernel launch */
+int nbody_set_profiling(NbodyHandle* h, int on); /* HIP events around the force-kernel launches: 0 off, 1 every launch, k > 1 every k-th (an
+                                                    event pair costs the stream ~11 us; the statistics then cover the bracketed launches) */
 int nbody_stats(NbodyHandle* h, NbodyStats* out);
 int nbody_reset_stats(NbodyHandle* h);
 /* f64 kinetic and potential energy of this rank's view (world_size == 1: the whole system),

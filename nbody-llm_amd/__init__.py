@@ -410,8 +410,9 @@ class Simulation:
     def sync(self):
         self._check(lib.nbody_sync(self._h))
 
-    def set_profiling(self, on: bool):
-        self._check(lib.nbody_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, on):
+        """False / True: HIP events around every force-kernel launch; an int k > 1: around every k-th."""
+        self._check(lib.nbody_set_profiling(self._h, int(on)))
 
     def stats(self) -> NbodyStats:
         s = NbodyStats()

@@ -219,7 +219,11 @@ struct ForceTimer {  // HIP events around a force-kernel launch, on the launch s
     NbodyHandle* h;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     explicit ForceTimer(NbodyHandle* hh) : h(hh) {
+        h->timed_this = false;
         if (!h->profiling) return;
+        // (an event pair costs the stream ~11 us: with nbody_set_profiling(h, k > 1) only every k-th launch is bracketed)
+        if (h->profile_every > 1 && (h->profile_tick++ % unsigned(h->profile_every)) != 0) return;
+        h->timed_this = true;
         if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
         else {
             if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) { ev = {nullptr, nullptr}; return; }
@@ -382,7 +386,7 @@ int bf_forces(NbodyHandle* h) {
     }
     HIP_TRY(h, hipGetLastError());
     // (NbodyStats::interactions is counted on the device from the live counts: Shard::inter)
-    if (tot > 0 && h->profiling) h->stats.force_kernel_interactions += timed;
+    if (tot > 0 && h->timed_this) h->stats.force_kernel_interactions += timed;
     return NBODY_OK;
 }
 
@@ -1514,6 +1518,8 @@ int nbody_sync(NbodyHandle* h) {
 int nbody_set_profiling(NbodyHandle* h, int on) {
     if (!h) return NBODY_ERR_INVALID;
     h->profiling = on != 0;
+    h->profile_every = on > 1 ? on : 1;
+    h->profile_tick = 0;
     return NBODY_OK;
 }
 

@@ -118,6 +118,9 @@ struct NbodyHandle {
     // diagnostics
     NbodyStats stats{};
     bool profiling = false;
+    int profile_every = 1;       // bracket every k-th force-kernel launch with events (nbody_set_profiling(h, k))
+    unsigned profile_tick = 0;
+    bool timed_this = false;     // the launch under way is one of the bracketed ones
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
     double* d_energy = nullptr;
     size_t energy_blocks = 0;

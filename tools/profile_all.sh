@@ -29,7 +29,7 @@ pmc() {  # name, counter, bench args...
 trace bf65536
 trace bh65536_host --workload bh --tree host
 trace bh65536_device --workload bh --tree device
-python3 "$R/tools/rocpd_timeline.py" "$(find "$OUT/bh65536_device" -name '*_results.db' | head -1)" k_tree_keys 20 > "$OUT/bh65536_device_step_timeline.txt" || true
+python3 "$R/tools/rocpd_timeline.py" "$(find "$OUT/bh65536_device" -name '*_results.db' | head -1)" k_tree_keys 120 > "$OUT/bh65536_device_step_timeline.txt" || true
 : > "$OUT/pmc_summary.txt"
 pmc pmc_fetch_bf FETCH_SIZE
 pmc pmc_write_bf WRITE_SIZE
