@@ -14,6 +14,8 @@ struct Tuning {
     int cross_sym = 1;          // sharded fast math: 1 = every pair between shards once (partial sums travel back), 0 = one-sided  [NBODY_CROSS_SYM]
     int sym_packed = 1;         // 1: packed-fp32 pair evaluation (pair_evals_pk), 0: scalar                                       [NBODY_SYM_PACKED]
     int bf_fast_variant = 0;    // 0: symmetric kernels where they apply, 1..: the LDS-tiled one-sided forms (kernels_bf.hip)       [NBODY_BF_VARIANT]
+    int bh_walk_duo = -1;       // Barnes-Hut fast walk: bodies of the tree order per lane sharing their node fetches (k_bh_walk_duo):
+                                // -1 from the body count (walk_plan), 0 / 1 one body per lane (k_bh_walk), 2 3 4 6 8                              [NBODY_BH_DUO]
     int let_list_div = 4;       // spatial shards: export / import buffers start at (slice node capacity) / this (they grow when a step needs more)
     int sym_wpb = 4;            // k_bf_sym: waves per workgroup: 4 (default), 8, 12 or 16                                           [NBODY_SYM_WPB]
     int sym_rounds = 1;         // k_bf_sym: rounds of workgroups per CU
@@ -36,6 +38,12 @@ struct Tuning {
     int sym_debug = 0;          // 4: in-kernel cycle stamps (tools/sym_cycles.py); 5-7: timing experiments that do not compute the forces
 };
 const Tuning& tuning();                 // of the handle this thread is serving; the defaults outside a call
+// The fast Barnes-Hut walk's shape for `n_order` bodies (one launch: bodies per lane x node-range segments), from the sweep
+// profiles/r03_bh_walk_plan_sweep.txt: the walk is bound by the L1's address rate for divergent gathers, neighbours in tree
+// order visit almost the same nodes, so a lane that walks several of them in lockstep fetches their UNION once -- as many
+// per lane as still leaves ~32 768 waves' worth of (lane groups x segments) for the chip.
+struct WalkPlan { int bodies_per_lane; int segments; };
+WalkPlan walk_plan(size_t n_order, bool fast_math, int max_segments, float theta2);
 void bind_tuning(const Tuning* t);      // (nullptr: back to the defaults)
 
 // Device-resident body state of one shard.  Positions of ALL shards live in `pos_all`

@@ -183,6 +183,106 @@ __global__ __launch_bounds__(BLOCK) void k_bh_walk(const NodeDev* __restrict__ n
     }
 }
 
+// Two bodies per lane (round 3).  What bounds k_bh_walk is the L1's address rate for divergent gathers, and
+// bodies that are neighbours in tree order visit almost the same nodes.  Here a lane walks TWO consecutive bodies of the
+// tree order in lockstep: each has its own next index, the lane visits the smaller one, fetches that record ONCE and
+// evaluates it for whichever of the two is due there.  Per body these are exactly the opening tests, in exactly the
+// order, of its own walk (same sums, same counters); per lane the loads are the UNION of the two sequences instead of
+// their sum.
+template <bool FAST, bool DIRECT>
+__device__ __forceinline__ int duo_visit(const float4 A, const float2 B, int i, const float4 p, float g, float eps2, float theta2,
+                                         float& ax, float& ay, float& az, unsigned int& n_acc, unsigned int& n_vis) {
+    const float rx = A.x - p.x, ry = A.y - p.y, rz = A.z - p.z;        // :190
+    const float r2 = (rx * rx + ry * ry) + rz * rz;                     // :191
+    const int skip = __float_as_int(B.y);
+    ++n_vis;
+    if (DIRECT) {
+        if (r2 < 1e-10f) return skip;                                   // llm :933-935
+        if (B.x < theta2 * r2 || skip == i + 1) {                       // llm :938, :958-972
+            float k;
+            if (FAST) { const float rinv = __builtin_amdgcn_rsqf(r2 + eps2); k = (g * A.w) * ((rinv * rinv) * rinv); }
+            else { const float inv_r = 1.0f / __builtin_sqrtf(r2 + eps2); const float inv_r3 = inv_r * inv_r * inv_r; k = g * A.w * inv_r3; }
+            ax += rx * k; ay += ry * k; az += rz * k;
+            ++n_acc;
+            return skip;
+        }
+        return i + 1;
+    }
+    if (B.x < theta2 * r2) {                                            // :192
+        float k;
+        if (FAST) { const float rinv = __builtin_amdgcn_rsqf(r2 + eps2); k = (g * A.w) * ((rinv * rinv) * rinv); }
+        else { const float r_dist = __builtin_sqrtf(r2 + eps2); const float r_cubed = r_dist * r_dist * r_dist; k = ((g * A.w) / r_cubed); }
+        ax += rx * k; ay += ry * k; az += rz * k;
+        ++n_acc;
+        return skip;
+    }
+    return i + 1;
+}
+template <bool FAST, bool DIRECT, int BLOCK, int BPL>
+__global__ __launch_bounds__(BLOCK) void k_bh_walk_duo(const NodeDev* __restrict__ nodes, int n_nodes, const int* __restrict__ order, int n_order,
+                                                       const float4* __restrict__ own_pos, float4* __restrict__ acc, float g, float eps2,
+                                                       float theta2, unsigned long long* __restrict__ counters, WalkSplit split) {
+    const int t = blockIdx.x * BLOCK + threadIdx.x;   // the bodies at places BPL t .. BPL t + BPL - 1 of the tree order
+    int seg = blockIdx.y;
+    if (split.diag_first) {
+        const int K = gridDim.y;
+        const int diag = int((long long)blockIdx.x * K / gridDim.x);
+        const int kk = blockIdx.y;
+        const int off = (kk & 1) ? (kk + 1) / 2 : -(kk / 2);
+        seg = ((diag + off) % K + K) % K;
+    }
+    if (split.poison && *split.poison) return;
+    if (split.n_order_dev) n_order = min(n_order, *split.n_order_dev);
+    const int s1 = split.first[seg + 1];
+    unsigned int n_acc = 0, n_vis = 0;
+    const int t0 = BPL * t;
+    if (t0 < n_order) {
+        float4 p[BPL];
+        float ax[BPL], ay[BPL], az[BPL];
+        unsigned int v[BPL];
+        int nx[BPL], body[BPL];
+        int i = s1;
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) {
+            const bool live = t0 + q < n_order;
+            body[q] = order[live ? t0 + q : t0];
+            p[q] = own_pos[body[q]];
+            ax[q] = ay[q] = az[q] = 0.f;
+            v[q] = 0;
+            nx[q] = live ? walk_entry<DIRECT>(nodes, split, seg, p[q], theta2) : s1;
+            i = min(i, nx[q]);
+        }
+        while (i < s1) {
+            const float4 A = nodes[i].a;
+            const float2 B = *reinterpret_cast<const float2*>(&nodes[i].b);
+            asm volatile("" :: "v"(A.w), "v"(B.y));   // (both loads whole and ahead of the branches: see k_bh_walk)
+            int nxt = s1;
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                if (nx[q] == i) nx[q] = duo_visit<FAST, DIRECT>(A, B, i, p[q], g, eps2, theta2, ax[q], ay[q], az[q], n_acc, v[q]);
+                nxt = min(nxt, nx[q]);
+            }
+            i = nxt;
+        }
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) {
+            n_vis += v[q];
+            if (t0 + q < n_order)
+                *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + (t0 + q) : acc + body[q]) =
+                    make_float4(ax[q], ay[q], az[q], split.store_work ? float(v[q]) : 0.f);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_acc += __shfl_down(n_acc, off);
+        n_vis += __shfl_down(n_vis, off);
+    }
+    if ((threadIdx.x & 63) == 0 && counters) {
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1);
+        atomicAdd(&counters[2 * slot], (unsigned long long)n_acc);
+        atomicAdd(&counters[2 * slot + 1], (unsigned long long)n_vis);
+    }
+}
+
 #ifdef NBODY_TUNING   // ---- experimental walks (variants 1 and 2): measured, slower, kept reproducible in the tuning build only
 // Wave-cooperative form of the same walk.  The 64 lanes of a wave hold 64 neighbouring bodies
 // (tree order) and step through the UNION of their node sequences together: the node index is
@@ -960,6 +1060,18 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
 #ifdef NBODY_TUNING   // the experimental walks (fast math only; 1 and 2: reference leaf rule only) and the stamped instantiations
     launched = launch_walk_variant(s, sh, t, g, g_soft2, theta2, fast_math, counters, leaf_direct, sp, grid);
 #endif
+    const int bpl = walk_plan(size_t(t.n_order), fast_math != 0, 1 << 20, theta2).bodies_per_lane;
+    if (!launched && bpl >= 2) {   // several bodies per lane (k_bh_walk_duo)
+        const int groups = (t.n_order + bpl - 1) / bpl;
+#define DUO(BLK, BPL, ...) hipLaunchKernelGGL((k_bh_walk_duo<__VA_ARGS__, BLK, BPL>), dim3((groups + BLK - 1) / BLK, t.n_split), dim3(BLK), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
+#define DUO_B(BLK, BPL) do { if (leaf_direct) { if (fast_math) DUO(BLK, BPL, true, true); else DUO(BLK, BPL, false, true); } else { if (fast_math) DUO(BLK, BPL, true, false); else DUO(BLK, BPL, false, false); } } while (0)
+#define DUO_A(BLK) do { if (bpl == 8) DUO_B(BLK, 8); else if (bpl == 6) DUO_B(BLK, 6); else if (bpl == 4) DUO_B(BLK, 4); else if (bpl == 3) DUO_B(BLK, 3); else DUO_B(BLK, 2); } while (0)
+        if (t.n_split <= 2) DUO_A(256); else DUO_A(64);
+#undef DUO_A
+#undef DUO_B
+#undef DUO
+        launched = true;
+    }
     if (!launched) {
 #define WALK(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), grid, dim3(kWalkBlock), 0, s, reinterpret_cast<const NodeDev*>(t.nodes), t.n_nodes, t.order, t.n_order, sh.own_pos(), sh.acc, g, g_soft2, theta2, counters, sp)
         if (t.n_split <= 2) {

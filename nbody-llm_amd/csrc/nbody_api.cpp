@@ -567,8 +567,7 @@ int bh_forces(NbodyHandle* h) {
         // ~3 waves per wave slot of the chip (256 CUs x 32), handed out heaviest first (nbody::tuning().bh_walk_order): the launch
         // lasts as long as its slowest wave, and smaller pieces started in the right order shorten that tail
         // (N = 65 536: 24 segments 0.310 ms, 8 segments 0.336 ms; tools/tune_bh_order.py)
-        int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
-        K = std::max(1, std::min(kMaxSplit, K));
+        int K = nbody::walk_plan(n_order, h->cfg.math_mode != NBODY_MATH_STRICT, kMaxSplit, h->theta2).segments;
         // strict math is the parity path: one segment, so every lane adds in the reference's order (bit-exact)
         if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody::tuning().bh_walk_split <= 0) K = 1;
         while (nbody::tuning().bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > h->tree.n_nodes) K /= 2;   // (a pinned split is taken as given)
@@ -712,8 +711,7 @@ int bh_walk_device_tree(NbodyHandle* h, bool* fell_back) {
         HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
         HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
     }
-    int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + (n_order + 63) / 64 - 1) / std::max<size_t>(1, (n_order + 63) / 64));
-    K = std::max(1, std::min(kMaxSplit, K));
+    int K = nbody::walk_plan(n_order, h->cfg.math_mode != NBODY_MATH_STRICT, kMaxSplit, h->theta2).segments;
     if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody::tuning().bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
     while (nbody::tuning().bh_walk_split <= 0 && K > 1 && K * 16 > n_nodes) K /= 2;
     if (n_order == 0) K = 1;
@@ -791,9 +789,7 @@ int bh_walk_device_tree_async(NbodyHandle* h) {
         HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
         HIP_TRY(h, hipHostMalloc(&h->h_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int), hipHostMallocDefault));
     }
-    const size_t groups = std::max<size_t>(1, (n_upper + 63) / 64);
-    int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + groups - 1) / groups);
-    K = std::max(1, std::min(kMaxSplit, K));
+    int K = nbody::walk_plan(n_upper, h->cfg.math_mode != NBODY_MATH_STRICT, kMaxSplit, h->theta2).segments;
     if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody::tuning().bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
     while (nbody::tuning().bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > n_upper) K /= 2;   // (a tree has at least as many nodes as bodies)
     if (n_upper == 0) K = 1;
@@ -1157,7 +1153,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
         nbody::Tuning& t = h->tune;
         const struct { const char* env; int* knob; } table[] = {
             {"NBODY_BF_VARIANT", &t.bf_fast_variant}, {"NBODY_CROSS_SYM", &t.cross_sym}, {"NBODY_SYM_PACKED", &t.sym_packed},
-            {"NBODY_BH_SPLIT", &t.bh_walk_split}, {"NBODY_SYM_WPB", &t.sym_wpb},
+            {"NBODY_BH_SPLIT", &t.bh_walk_split}, {"NBODY_SYM_WPB", &t.sym_wpb}, {"NBODY_BH_DUO", &t.bh_walk_duo},
 #ifdef NBODY_TUNING
             {"NBODY_BH_VARIANT", &t.bh_walk_variant}, {"NBODY_BH_HOT", &t.bh_hot_cap}, {"NBODY_BH_LDS_BLOCK", &t.bh_walk_lds_block},
 #endif
@@ -1789,7 +1785,7 @@ namespace {
 struct Knob { const char* name; int nbody::Tuning::*field; bool tuning_build_only; };
 const Knob kKnobs[] = {
     {"cross_sym", &nbody::Tuning::cross_sym, false}, {"sym_packed", &nbody::Tuning::sym_packed, false},
-    {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false}, {"let_list_div", &nbody::Tuning::let_list_div, false},
+    {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false}, {"let_list_div", &nbody::Tuning::let_list_div, false}, {"bh_walk_duo", &nbody::Tuning::bh_walk_duo, false},
     {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_k", &nbody::Tuning::sym_k, false},
     {"sym_min_bodies", &nbody::Tuning::sym_min_bodies, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
     {"cross_slots", &nbody::Tuning::cross_slots, false}, {"cross_ipt", &nbody::Tuning::cross_ipt, false},
