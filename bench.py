@@ -200,9 +200,13 @@ def bh_roofline(n_local, kernel_ms, launches, visits_per_launch, tree):
     lines = per_visit * vpc if per_visit else None
     rows = ceil.get("by_lanes_per_record_visits_per_cycle_per_cu") or {}
     return {
-        "bound": "l1-ta", "kernel": "k_bh_walk (+ k_bh_reduce)", "achieved": lines, "peak": peak_lines,
+        "bound": "l1-ta", "kernel": (pj.get("kernel") or "k_bh_walk") + " (+ k_bh_reduce)", "achieved": lines, "peak": peak_lines,
         "unit": "L1 cache-line accesses/cycle/CU", "frac": (lines / peak_lines) if (lines and peak_lines) else None,
         "traffic": traffic,
+        "note": "since round 3 a lane walks several neighbouring bodies and fetches the union of their node sequences once: "
+                "l1_line_accesses_per_visit < 1 is that sharing, and visits_per_cycle_per_cu may exceed the one-lane-per-record "
+                "ceiling; `frac` is the L1 address rate actually used (what bounded the one-body walk), not a quality score of "
+                "the faster kernel (DESIGN.md section 3.4)",
         "avg_kernel_ms": avg_ms, "launches_timed": int(launches), "visits_per_launch": visits_per_launch,
         "clock_hz_assumed": CLOCK_HZ, "l1_line_accesses_per_visit": per_visit,
         "visits_per_cycle_per_cu": vpc,

@@ -228,6 +228,8 @@ void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_
 
 // the walk's {accepted, visited} counters: this many u64 pairs, to be summed by the reader
 #define NBODY_WALK_COUNTER_SLOTS 1024u
+// split points and their ancestors from the node array itself (first [n_split + 1], n_anc [n_split], anc [n_split][192]; range: device {begin, end})
+void launch_walk_split_scan(hipStream_t s, const float4* nodes, const int* range, int n_split, int* first, int* n_anc, int* anc, int first_given = 0);
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters /* [NBODY_WALK_COUNTER_SLOTS][2]: accepted, visited */, int leaf_direct = 0,
                     const float* kick_dt = nullptr /* fuse integrate_after_force into the plane reduction */,

@@ -923,19 +923,19 @@ __global__ __launch_bounds__(256) void k_bh_reduce(const float4* __restrict__ pl
                                                    const int* __restrict__ order, int n_order,
                                                    float4* __restrict__ acc, float4* __restrict__ pos,
                                                    float4* __restrict__ vel, float dt, int* __restrict__ poison,
-                                                   const int* __restrict__ n_order_dev) {
+                                                   const int* __restrict__ n_order_dev, int store_work) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (poison && *poison) return;
     if (KICK && poison && t == 0) atomicAdd(poison + 1, 1);   // a step of an unsynchronised run is complete
     if (n_order_dev) n_order = min(n_order, *n_order_dev);
     if (t >= n_order) return;
     const int b = order[t];
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
     for (int k = 0; k < n_seg; ++k) {  // segment order = the order the single walk adds them in
         const float4 v = planes[size_t(k) * plane_stride + t];   // (by tree-order position: coalesced; by body it was a gather, 18 us)
-        sx += v.x; sy += v.y; sz += v.z;
+        sx += v.x; sy += v.y; sz += v.z; sw += v.w;
     }
-    acc[b] = make_float4(sx, sy, sz, 0.f);
+    acc[b] = make_float4(sx, sy, sz, store_work ? sw : 0.f);   // (w: the body's visit count, a sum of small integers: exact)
     if (KICK) {
         float4 p = pos[b], v = vel[b];
         v.x += sx * dt;                 // shared.rs:144
@@ -956,28 +956,28 @@ template <bool KICK, int Q>
 __global__ __launch_bounds__(64 * Q) void k_bh_reduce_split(const float4* __restrict__ planes, int n_seg, size_t plane_stride,
                                                             const int* __restrict__ order, int n_order, float4* __restrict__ acc,
                                                             float4* __restrict__ pos, float4* __restrict__ vel, float dt,
-                                                            int* __restrict__ poison, const int* __restrict__ n_order_dev) {
-    __shared__ float part[Q][3][64];
+                                                            int* __restrict__ poison, const int* __restrict__ n_order_dev, int store_work) {
+    __shared__ float part[Q][4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
     if (poison && *poison) return;
     if (KICK && poison && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(poison + 1, 1);   // a step of an unsynchronised run is complete
     if (n_order_dev) n_order = min(n_order, *n_order_dev);
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
     if (t < n_order) {
         const int k0 = n_seg * q / Q, k1 = n_seg * (q + 1) / Q;
         for (int k = k0; k < k1; ++k) {
             const float4 v = planes[size_t(k) * plane_stride + t];
-            sx += v.x; sy += v.y; sz += v.z;
+            sx += v.x; sy += v.y; sz += v.z; sw += v.w;
         }
     }
-    part[q][0][lane] = sx; part[q][1][lane] = sy; part[q][2][lane] = sz;
+    part[q][0][lane] = sx; part[q][1][lane] = sy; part[q][2][lane] = sz; part[q][3][lane] = sw;
     __syncthreads();
     if (q != 0 || t >= n_order) return;
-    sx = part[0][0][lane]; sy = part[0][1][lane]; sz = part[0][2][lane];
-    for (int w = 1; w < Q; ++w) { sx += part[w][0][lane]; sy += part[w][1][lane]; sz += part[w][2][lane]; }
+    sx = part[0][0][lane]; sy = part[0][1][lane]; sz = part[0][2][lane]; sw = part[0][3][lane];
+    for (int w = 1; w < Q; ++w) { sx += part[w][0][lane]; sy += part[w][1][lane]; sz += part[w][2][lane]; sw += part[w][3][lane]; }
     const int b = order[t];
-    acc[b] = make_float4(sx, sy, sz, 0.f);
+    acc[b] = make_float4(sx, sy, sz, store_work ? sw : 0.f);
     if (KICK) {
         float4 p = pos[b], v = vel[b];
         v.x += sx * dt; v.y += sy * dt; v.z += sz * dt;                                       // shared.rs:144
@@ -1039,6 +1039,34 @@ static bool launch_walk_variant(hipStream_t s, const Shard& sh, const TreeDev& t
 }
 #endif  // NBODY_TUNING
 
+// Split points of ANY pre-order node array with skip links (spatial shards: the array of held nodes has no build arrays to
+// take them from): segment k starts at node range[0] + (range[1] - range[0]) k / n_split; its ancestors are found by
+// walking down from the root -- a node whose skip link lies beyond t holds t in its subtree.  One thread per split point.
+__global__ void k_walk_split_scan(const NodeDev* __restrict__ nodes, const int* __restrict__ range, int n_split, int* __restrict__ first,
+                                  int* __restrict__ n_anc, int* __restrict__ anc, int first_given) {
+    const int s = threadIdx.x;
+    if (s >= n_split) return;
+    const int b = range[0], e = range[1];
+    const int t = first_given ? first[s] : b + int((long long)(e - b) * s / n_split);
+    if (!first_given) {
+        first[s] = t;
+        if (s == n_split - 1) first[n_split] = e;
+    }
+    int i = b, na = 0;
+    while (i < t && na < kMaxAnc) {
+        const int skip = __float_as_int(nodes[i].b.y);
+        if (skip > t) { anc[s * kMaxAnc + na++] = i; i = i + 1; }
+        else i = skip;
+    }
+    n_anc[s] = na;
+}
+// first_given: first[0 .. n_split] are the caller's (spatial shards cut at GLOBAL node indices, so that what a rank holds
+// beyond the nodes its bodies visit does not move the cuts); otherwise equal parts of the array
+void launch_walk_split_scan(hipStream_t s, const float4* nodes, const int* range, int n_split, int* first, int* n_anc, int* anc, int first_given) {
+    hipLaunchKernelGGL(k_walk_split_scan, dim3(1), dim3(64 * ((n_split + 63) / 64)), 0, s, reinterpret_cast<const NodeDev*>(nodes), range, n_split,
+                       first, n_anc, anc, first_given);
+}
+
 void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, float g_soft2, float theta2,
                     int fast_math, unsigned long long* counters, int leaf_direct, const float* kick_dt, int* kicked) {
     if (kicked) *kicked = 0;
@@ -1091,21 +1119,21 @@ void launch_bh_walk(hipStream_t s, const Shard& sh, const TreeDev& t, float g, f
         const dim3 rg((t.n_order + 63) / 64);
         if (kick_dt) {
             hipLaunchKernelGGL((k_bh_reduce_split<true, 4>), rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order, t.n_order,
-                               sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.poison, t.n_order_dev);
+                               sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.poison, t.n_order_dev, t.store_work);
             if (kicked) *kicked = 1;
         } else {
             hipLaunchKernelGGL((k_bh_reduce_split<false, 4>), rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order, t.n_order,
-                               sh.acc, sh.own_pos(), sh.vel, 0.f, sh.poison, t.n_order_dev);
+                               sh.acc, sh.own_pos(), sh.vel, 0.f, sh.poison, t.n_order_dev, t.store_work);
         }
     } else if (t.n_split > 1) {
         const dim3 rg((t.n_order + 255) / 256);
         if (kick_dt) {
             hipLaunchKernelGGL(k_bh_reduce<true>, rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order,
-                               t.n_order, sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.poison, t.n_order_dev);
+                               t.n_order, sh.acc, sh.own_pos(), sh.vel, *kick_dt, sh.poison, t.n_order_dev, t.store_work);
             if (kicked) *kicked = 1;
         } else {
             hipLaunchKernelGGL(k_bh_reduce<false>, rg, dim3(256), 0, s, t.split_planes, t.n_split, t.split_stride, t.order,
-                               t.n_order, sh.acc, sh.own_pos(), sh.vel, 0.f, sh.poison, t.n_order_dev);
+                               t.n_order, sh.acc, sh.own_pos(), sh.vel, 0.f, sh.poison, t.n_order_dev, t.store_work);
         }
     }
 }

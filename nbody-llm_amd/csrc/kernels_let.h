@@ -86,7 +86,8 @@ size_t pack_blocks(int local_cap);
 // the array the walk runs over: the rank's slice and the staged imports (in_n[q] records from rank q, one rank after the
 // other) in global-index order, links translated to positions; split = {0, nodes held}.  staged_upper >= the imports' total.
 void launch_assemble(hipStream_t s, const float4* slice, int local_cap, const LetRecord* staged, int staged_upper, const int* in_n, const int* info,
-                     const int* offsets, const int* top_index, const float4* top_nodes, int G, int me, void* layout, int* split, float4* held);
+                     const int* offsets, const int* top_index, const float4* top_nodes, int G, int me, void* layout, int* split, float4* held,
+                     int n_split, int* seg_first /* n_split > 1: [n_split + 1] where the walk's segments start (global cuts) */);
 size_t layout_bytes();
 
 }  // namespace let

@@ -656,6 +656,16 @@ __global__ __launch_bounds__(256) void k_let_place_halo(const LetRecord* __restr
     held[2 * size_t(pos)] = rec.a;
     held[2 * size_t(pos) + 1] = rec.b;
 }
+// the walk's node-range segments start at GLOBAL indices total * k / n_split, wherever those fall in what this rank holds:
+// the cuts -- and with them the grouping of every body's partial sums -- do not depend on what was exported beyond need
+__global__ void k_let_seg_first(const LetRecord* __restrict__ staged, const int* __restrict__ in_n, const int* __restrict__ offsets,
+                                const HaloLayout* __restrict__ lay_p, int G, int me, int n_split, int* __restrict__ first) {
+    const int k = threadIdx.x;
+    if (k > n_split) return;
+    const HaloLayout lay = *lay_p;
+    const int t = int((long long)offsets[G] * k / n_split);
+    first[k] = k == n_split ? lay.total : held_before(t, offsets, in_n, lay, staged, G, me);
+}
 // my own spanning cells: their links lead into later ranks' slices (after k_let_place_own, which gave them a local link)
 __global__ void k_let_place_top(const float4* __restrict__ top_nodes, const int* __restrict__ top_index, const LetRecord* __restrict__ staged,
                                 const int* __restrict__ in_n, const int* __restrict__ offsets, const HaloLayout* __restrict__ lay_p, int G, int me,
@@ -750,13 +760,15 @@ void launch_pack(hipStream_t s, int local_cap, const int* info, const float4* sl
 }
 size_t pack_blocks(int local_cap) { return size_t(grid_for(local_cap, kPackThreads).x); }
 void launch_assemble(hipStream_t s, const float4* slice, int local_cap, const LetRecord* staged, int staged_upper, const int* in_n, const int* info,
-                     const int* offsets, const int* top_index, const float4* top_nodes, int G, int me, void* layout, int* split, float4* held) {
+                     const int* offsets, const int* top_index, const float4* top_nodes, int G, int me, void* layout, int* split, float4* held,
+                     int n_split, int* seg_first) {
     HaloLayout* lay = static_cast<HaloLayout*>(layout);
     hipLaunchKernelGGL(k_let_layout, dim3(1), dim3(64), 0, s, in_n, info, G, me, lay, split);
     hipLaunchKernelGGL(k_let_place_own, grid_for(local_cap, 256), dim3(256), 0, s, slice, lay, held);
     if (staged_upper > 0)
         hipLaunchKernelGGL(k_let_place_halo, grid_for(staged_upper, 256), dim3(256), 0, s, staged, in_n, offsets, lay, G, me, held);
     hipLaunchKernelGGL(k_let_place_top, dim3(1), dim3(64), 0, s, top_nodes, top_index, staged, in_n, offsets, lay, G, me, held);
+    if (n_split > 1) hipLaunchKernelGGL(k_let_seg_first, dim3(1), dim3(128), 0, s, staged, in_n, offsets, lay, G, me, n_split, seg_first);
 }
 size_t layout_bytes() { return sizeof(HaloLayout); }
 

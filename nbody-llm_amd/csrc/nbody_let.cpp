@@ -67,6 +67,9 @@ struct State {
     void* d_layout = nullptr;
     int* d_zero = nullptr;        // [1] = 0: the slice is emitted with local indices
     size_t staged = 0;            // emulation: records in the staging buffer so far
+    int* d_seg_first = nullptr;   // [kWalkMaxSplit + 1] first node of every walk segment | [kWalkMaxSplit] ancestor counts | [kWalkMaxSplit][192] ancestors
+    float4* d_walk_planes = nullptr;   // [segments][stride] the segments' partial accelerations
+    size_t walk_planes_cap = 0;
     uint64_t send_regrown = 0;    // times the export buffer had to grow (and the lists were written again)
     int* d_order = nullptr;
     int* d_tree_info = nullptr;   // [4] of the local build
@@ -108,6 +111,7 @@ struct State {
 namespace {
 
 constexpr long long kNoClamp = 0x7fffffffLL;   // the lists travel whole (exchange_layout's clamp)
+constexpr int kWalkMaxSplit = 64;              // node-range segments of the walk (kernels_bh.hip WalkSplit), at most
 
 int fail(NbodyHandle* h, int code, const std::string& msg) { h->err = msg; return code; }
 
@@ -338,13 +342,18 @@ int phase3(NbodyHandle* h, State& s) {
 int phase4(NbodyHandle* h, State& s, float dt, bool kick) {
     Shard& sh = h->sh;
     PhaseTimer timer(h, s, 4);
+    // the walk's shape for this many bodies (kernels.h walk_plan): bodies per lane inside launch_bh_walk, node-range segments here
+    // -- a rank with 10^5-10^6 bodies is a few thousand waves at one segment, not enough to fill the chip
+    const bool fast = h->cfg.math_mode != NBODY_MATH_STRICT;
+    int K = h->n_local > 0 ? walk_plan(h->n_local, fast, kWalkMaxSplit, h->theta2).segments : 1;
+    while (K > 1 && size_t(K) * 16 > h->n_local) K /= 2;   // (a tree has at least as many nodes as bodies; tiny ranks walk in one piece)
     // the nodes this rank holds, in global-index order, links = positions; first[] of the unsplit walk = {0, nodes held}
     {
         size_t staged_upper = 0;
         for (int r = 0; r < s.G; ++r) { s.h_in_pin[r] = s.recv_n[r]; staged_upper += size_t(std::max(0, s.recv_n[r])); }
         HIP_TRY(h, hipMemcpyAsync(s.d_in_n, s.h_in_pin, sizeof(int) * size_t(s.G), hipMemcpyHostToDevice, h->stream));
         launch_assemble(h->stream, s.d_slice, s.local_cap, s.d_let_recv, int(staged_upper), s.d_in_n, s.d_tree_info, s.d_offsets, s.d_top_index,
-                        s.d_top_nodes, s.G, s.me, s.d_layout, s.d_split, s.d_held);
+                        s.d_top_nodes, s.G, s.me, s.d_layout, s.d_split, s.d_held, K, s.d_seg_first);
     }
     TreeDev td;
     td.nodes = s.d_held; td.n_nodes = int(std::min<size_t>(s.held_cap, 0x7fffffff));
@@ -352,17 +361,34 @@ int phase4(NbodyHandle* h, State& s, float dt, bool kick) {
     td.n_order_dev = sh.own_count();
     td.poison = s.d_flags;
     td.store_work = 1;
-    td.n_split = 1;
-    td.split_first = s.d_split;
-    td.split_n_anc = s.d_split + 2;
-    td.split_anc = s.d_split + 2;
-    {
-        int kicked = 0;
-        launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2, 1, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT,
-                       nullptr, &kicked);
+    td.n_split = K;
+    if (K > 1) {
+        const size_t stride = (h->n_local + 1023) / 1024 * 1024;
+        if (size_t(K) * stride > s.walk_planes_cap) {
+            if (s.d_walk_planes) (void)hipFree(s.d_walk_planes);
+            s.d_walk_planes = nullptr; s.walk_planes_cap = 0;
+            const size_t want = size_t(K) * stride + size_t(K) * stride / 8;
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_walk_planes), want * sizeof(float4)));
+            s.walk_planes_cap = want;
+        }
+        // the segments start at global node indices total k / K (launch_assemble found where those fall in the held array); their
+        // ancestors come from the held array itself (the local build's arrays know the slice only)
+        launch_walk_split_scan(h->stream, s.d_held, s.d_split, K, s.d_seg_first, s.d_seg_first + kWalkMaxSplit + 1, s.d_seg_first + 2 * kWalkMaxSplit + 1, 1);
+        td.split_first = s.d_seg_first;
+        td.split_n_anc = s.d_seg_first + kWalkMaxSplit + 1;
+        td.split_anc = s.d_seg_first + 2 * kWalkMaxSplit + 1;
+        td.split_planes = s.d_walk_planes;
+        td.split_stride = stride;
+    } else {
+        td.split_first = s.d_split;          // {0, nodes held} (k_let_layout)
+        td.split_n_anc = s.d_split + 2;      // 0
+        td.split_anc = s.d_split + 2;
     }
+    int kicked = 0;
+    launch_bh_walk(h->stream, sh, td, h->g, h->g_soft * h->g_soft, h->theta2, fast ? 1 : 0, h->d_counters, h->cfg.leaf_mode == NBODY_LEAF_DIRECT,
+                   kick ? &dt : nullptr, &kicked);
     if (kick) {
-        launch_kick_drift(h->stream, sh, int(h->n_local), dt);   // integrate_after_force
+        if (!kicked) launch_kick_drift(h->stream, sh, int(h->n_local), dt);   // integrate_after_force (K > 1: it rode in the plane reduction)
         h->elapsed += dt;
         h->stats.steps += 1;
     }
@@ -416,6 +442,7 @@ int create(NbodyHandle* h) {
     if ((rc = dev_alloc(h, &s.d_pred, size_t(s.G) * s.G))) return rc;
     if ((rc = dev_alloc(h, &s.d_top_nodes, size_t(s.G) * kLevels * 2))) return rc;
     if ((rc = dev_alloc(h, &s.d_list_first, size_t(s.G) + 1))) return rc;
+    if ((rc = dev_alloc(h, &s.d_seg_first, size_t(2 * kWalkMaxSplit + 1 + kWalkMaxSplit * 192)))) return rc;
     if ((rc = dev_alloc(h, &s.d_in_n, size_t(s.G)))) return rc;
     if ((rc = dev_alloc(h, &s.d_zero, 1))) return rc;
     if ((rc = dev_alloc(h, reinterpret_cast<char**>(&s.d_layout), layout_bytes()))) return rc;
@@ -432,7 +459,7 @@ void destroy(NbodyHandle* h) {
     if (!s) return;
     void* dev[] = {s->d_bounds, s->d_bounds_scratch, s->d_weight_sum, s->d_send_mig, s->d_recv_mig, s->d_send_count, s->d_send_off, s->d_mig_cursor, s->d_mig_matrix, s->d_dest_of, s->d_new_count, s->d_flags, s->d_box_ord,
                    s->d_ends, s->d_edge, s->d_rb, s->d_offsets, s->d_top_index, s->d_split, s->d_slice, s->d_held, s->d_top_nodes, s->d_node_mask,
-                   s->d_block_n, s->d_in_n, s->d_layout, s->d_zero, s->d_list_first, s->d_order, s->d_tree_info,
+                   s->d_block_n, s->d_in_n, s->d_layout, s->d_zero, s->d_list_first, s->d_seg_first, s->d_walk_planes, s->d_order, s->d_tree_info,
                    s->d_ws, s->d_parent, s->d_depth, s->d_upper_ok, s->d_node_flags, s->d_let_count, s->d_let_send,
                    s->d_let_recv, s->d_let_matrix, h->sh.ids, s->d_report, s->d_pred, s->d_slot_out};
     for (void* p : dev) if (p) (void)hipFree(p);

@@ -23,7 +23,7 @@ def counter(section, kernel_sub):
     for line in m.group(1).splitlines():
         if kernel_sub in line:
             global last_kernel_name
-            last_kernel_name = re.search(r"(%s[^>]*>)" % re.escape(kernel_sub), line).group(1)
+            last_kernel_name = re.search(r"(%s\w*<[^>]*>)" % re.escape(kernel_sub.rstrip("<")), line).group(1)
             return float(line.split()[-1])
     return None
 
@@ -52,8 +52,8 @@ write("pmc_traffic_bf.json", {
     "source": f"tools/profile_all.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --no-cpu-baseline --no-bh --steps 10 --warmup 2",
 })
 for tree in ("host", "device"):
-    fz, wz = counter(f"pmc_fetch_bh_{tree}", "k_bh_walk<"), counter(f"pmc_write_bh_{tree}", "k_bh_walk<")
-    l1 = counter(f"pmc_l1_bh_{tree}", "k_bh_walk<")
+    fz, wz = counter(f"pmc_fetch_bh_{tree}", "k_bh_walk"), counter(f"pmc_write_bh_{tree}", "k_bh_walk")
+    l1 = counter(f"pmc_l1_bh_{tree}", "k_bh_walk")
     b = bench(f"pmc_l1_bh_{tree}")
     visits = b["bh"]["node_visits_per_step"]
     write(f"pmc_traffic_bh_{tree}.json", {
