@@ -311,7 +311,10 @@ __device__ __forceinline__ int walk_entry64(const Node64* __restrict__ nodes, co
     return sp.first[seg];
 }
 
-template <bool DIRECT>
+// BPL neighbouring bodies of the tree order per lane, walked in lockstep: the lane visits the smallest of their next
+// indices, fetches that 64-byte record once and evaluates it for whichever bodies are due there (kernels_bh.hip
+// k_bh_walk_duo: per body the same tests in the same order, the same sums; per lane the union of the sequences)
+template <bool DIRECT, int BPL>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_fast64(const Node64* __restrict__ nodes, int n_nodes, const int* __restrict__ order, int n_order,
                                                                const double4* __restrict__ pos, double4* __restrict__ acc, double g, double eps2,
                                                                double theta2, unsigned long long* __restrict__ counters, WalkSplit64 split) {
@@ -323,29 +326,50 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_fast64(const Node64* __r
     const int seg = ((diag + ((kk & 1) ? (kk + 1) / 2 : -(kk / 2))) % K + K) % K;
     const int s1 = split.first[seg + 1];
     unsigned int n_acc = 0, n_vis = 0;
-    if (t < n_order) {
-        const int b = order[t];
-        const double4 p = pos[b];
-        double ax = 0.0, ay = 0.0, az = 0.0;
-        int i = walk_entry64(nodes, split, seg, p, theta2, DIRECT);
+    const int t0 = BPL * t;
+    if (t0 < n_order) {
+        double4 p[BPL];
+        double ax[BPL], ay[BPL], az[BPL];
+        int nx[BPL], body[BPL];
+        int i = s1;
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) {
+            const bool live = t0 + q < n_order;
+            body[q] = order[live ? t0 + q : t0];
+            p[q] = pos[body[q]];
+            ax[q] = ay[q] = az[q] = 0.0;
+            nx[q] = live ? walk_entry64(nodes, split, seg, p[q], theta2, DIRECT) : s1;
+            i = min(i, nx[q]);
+        }
         while (i < s1) {
             const Node64 nd = nodes[i];
-            const double rx = nd.x - p.x, ry = nd.y - p.y, rz = nd.z - p.z;
-            const double r2 = (rx * rx + ry * ry) + rz * rz;
             const int skip = nd.skip;
-            ++n_vis;
-            if (DIRECT && r2 < 1e-10) { i = skip; continue; }
-            if (nd.w2 < theta2 * r2 || (DIRECT && skip == i + 1)) {
-                const double rinv = rsqrt(r2 + eps2);
-                const double k = (g * nd.m) * ((rinv * rinv) * rinv);
-                ax = fma(rx, k, ax); ay = fma(ry, k, ay); az = fma(rz, k, az);
-                ++n_acc;
-                i = skip;
-            } else {
-                i = i + 1;
+            int nxt = s1;
+#pragma unroll
+            for (int q = 0; q < BPL; ++q) {
+                if (nx[q] == i) {
+                    const double rx = nd.x - p[q].x, ry = nd.y - p[q].y, rz = nd.z - p[q].z;
+                    const double r2 = (rx * rx + ry * ry) + rz * rz;
+                    ++n_vis;
+                    if (DIRECT && r2 < 1e-10) nx[q] = skip;
+                    else if (nd.w2 < theta2 * r2 || (DIRECT && skip == i + 1)) {
+                        const double rinv = rsqrt(r2 + eps2);
+                        const double k = (g * nd.m) * ((rinv * rinv) * rinv);
+                        ax[q] = fma(rx, k, ax[q]); ay[q] = fma(ry, k, ay[q]); az[q] = fma(rz, k, az[q]);
+                        ++n_acc;
+                        nx[q] = skip;
+                    } else {
+                        nx[q] = i + 1;
+                    }
+                }
+                nxt = min(nxt, nx[q]);
             }
+            i = nxt;
         }
-        *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + t : acc + b) = make_double4(ax, ay, az, 0.0);
+#pragma unroll
+        for (int q = 0; q < BPL; ++q)
+            if (t0 + q < n_order)
+                *(split.n_seg > 1 ? split.planes + size_t(seg) * split.plane_stride + (t0 + q) : acc + body[q]) = make_double4(ax[q], ay[q], az[q], 0.0);
     }
     add_counts(counters, n_acc, n_vis);
 }
@@ -441,13 +465,15 @@ void launch_bh_walk(hipStream_t s, const Dev& d, const Node64* nodes, int n_node
                            stack, stack_stride);
 }
 void launch_bh_walk_fast(hipStream_t s, const Dev& d, const Node64* nodes, int n_nodes, const int* order, int n_order, double g, double eps2,
-                         double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split) {
+                         double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split, int bodies_per_lane) {
     if (n_order <= 0) return;
-    const dim3 grid(blocks_for(n_order, kWalkBlock), split.n_seg);
-    if (leaf_direct)
-        hipLaunchKernelGGL(k_bh_walk_fast64<true>, grid, dim3(kWalkBlock), 0, s, nodes, n_nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters, split);
-    else
-        hipLaunchKernelGGL(k_bh_walk_fast64<false>, grid, dim3(kWalkBlock), 0, s, nodes, n_nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters, split);
+    const int bpl = bodies_per_lane >= 6 ? 6 : bodies_per_lane >= 4 ? 4 : bodies_per_lane == 3 ? 3 : bodies_per_lane == 2 ? 2 : 1;
+    const dim3 grid(blocks_for((n_order + bpl - 1) / bpl, kWalkBlock), split.n_seg);
+#define WALK64(D, B) hipLaunchKernelGGL((k_bh_walk_fast64<D, B>), grid, dim3(kWalkBlock), 0, s, nodes, n_nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters, split)
+#define WALK64_B(D) do { if (bpl == 6) WALK64(D, 6); else if (bpl == 4) WALK64(D, 4); else if (bpl == 3) WALK64(D, 3); else if (bpl == 2) WALK64(D, 2); else WALK64(D, 1); } while (0)
+    if (leaf_direct) WALK64_B(true); else WALK64_B(false);
+#undef WALK64_B
+#undef WALK64
     if (split.n_seg > 1)
         hipLaunchKernelGGL(k_bh_reduce64, dim3(blocks_for(n_order, 256)), dim3(256), 0, s, split.planes, split.n_seg, split.plane_stride, order, n_order, d.acc);
 }

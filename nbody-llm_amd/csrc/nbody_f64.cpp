@@ -165,9 +165,8 @@ int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const 
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_split), kSplitInts * sizeof(int)));
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.h_split), kSplitInts * sizeof(int), hipHostMallocDefault));
     }
-    const size_t groups = std::max<size_t>(1, (size_t(n_order) + 63) / 64);
-    int K = nbody::tuning().bh_walk_split > 0 ? nbody::tuning().bh_walk_split : int((16384 + groups - 1) / groups);
-    K = std::max(1, std::min(kMaxSplit, K));
+    const nbody::WalkPlan plan = nbody::walk_plan(size_t(n_order), true, kMaxSplit, float(s.theta2));   // (bodies per lane x segments: kernels.h)
+    int K = plan.segments;
     while (nbody::tuning().bh_walk_split <= 0 && K > 1 && K * 16 > n_nodes) K /= 2;
     if (n_order == 0 || n_nodes <= 0) return NBODY_OK;
     int* first = s.d_split;
@@ -203,7 +202,7 @@ int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const 
     {
         ForceTimer t(h);
         launch_bh_walk_fast(h->stream, s.d, nodes, n_nodes, order, n_order, s.g, s.g_soft * s.g_soft, s.theta2, h->d_counters,
-                            h->cfg.leaf_mode == NBODY_LEAF_DIRECT ? 1 : 0, sp);
+                            h->cfg.leaf_mode == NBODY_LEAF_DIRECT ? 1 : 0, sp, std::min(3, plan.bodies_per_lane));   // (64-byte records, doubles in registers: beyond three per lane the f64 walk loses again -- tools/f64_walk_probe.py)
     }
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
