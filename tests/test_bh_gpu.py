@@ -154,6 +154,46 @@ def test_fast_math_walk_same_nodes(gpu, orc):
     assert rel_err(got["acceleration"], ref["acceleration"]) < 1e-5
 
 
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("leaf", ["reference", "direct"])
+@pytest.mark.parametrize("n,split", [(3, 1), (1001, 1), (4097, 8), (30000, 16)])
+def test_several_bodies_per_lane_walk_exactly_like_one(gpu, orc, n, split, leaf, f64):
+    """k_bh_walk_duo / k_bh_walk_fast64<BPL>: a lane walks 2, 3, 4, 6 or 8 neighbouring bodies of the tree order in lockstep
+    and fetches the union of their node sequences once.  Per body it evaluates the opening tests of its own walk in its
+    own order: with the same node-range segments the accelerations are the one-body-per-lane walk's BIT FOR BIT and the
+    accepted / visited counts are equal (and, with the host tree, the oracle's) -- for body counts that leave the last lane
+    half empty, both leaf rules, host and device tree, several steps with bodies leaving the box."""
+    nb = gpu
+    sd, st = sd_st(nb, theta2=0.25, g_soft=0.01)
+    ics = nb.plummer(n, seed=37, f64=f64)
+    box = ((0.0, 0.0, 0.0), 6.0)
+    ics = ics[(np.abs(ics["position"]) < 2.9).all(axis=1)]   # (inside the box to start with; some leave during the steps)
+    ics["velocity"] *= 30
+    for tree in (nb.TREE_HOST, nb.TREE_DEVICE):
+        out = {}
+        for bpl in (1, 2, 3, 4, 6, 8):
+            with nb.Simulation(ics, *box, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=tree,
+                               leaf_mode=nb.LEAF_DIRECT if leaf == "direct" else nb.LEAF_REFERENCE,
+                               tuning=dict(bh_walk_duo=bpl, bh_walk_split=split)) as sim:
+                sim.settings = st
+                sim.update_forces()
+                first = sim.get_points()
+                s1 = sim.stats()
+                sim.steps(3)
+                out[bpl] = (first, (s1.interactions, s1.node_visits), sim.get_points(), sim.stats())
+        word = np.uint64 if f64 else np.uint32
+        for bpl in (2, 3, 4, 6, 8):
+            assert out[bpl][1] == out[1][1], (tree, bpl)
+            assert np.array_equal(out[bpl][0]["acceleration"].view(word), out[1][0]["acceleration"].view(word)), (tree, bpl)
+            assert len(out[bpl][2]) == len(out[1][2])
+            for f in ("position", "velocity", "acceleration"):
+                assert np.array_equal(out[bpl][2][f].view(word), out[1][2][f].view(word)), (tree, bpl, f)
+            assert (out[bpl][3].interactions, out[bpl][3].node_visits) == (out[1][3].interactions, out[1][3].node_visits)
+        if tree == nb.TREE_HOST and leaf == "reference" and not f64:
+            ref = ics.copy().astype(orc.P32)
+            assert out[2][1] == orc.bh_update_forces(ref, sd, box[0], box[1], threads=4)
+
+
 def test_retain_in_a_tight_box(gpu, orc):
     nb = gpu
     box = ((0.0, 0.0, 0.0), 2.0)
