@@ -195,9 +195,12 @@ size_t tree_cat_bytes(size_t n_cap);
 TreeCat tree_cat_layout(void* buf, size_t n_cap);
 void launch_tree_cat(hipStream_t s, const Shard& sh, const TreeCat& c);
 int launch_tree_own_order(hipStream_t s, const int* order, const TreeCat& c, int n_total_upper, void* tmp, size_t tmp_bytes);
+// The walk's node-range split points ride in the emit's launch as extra workgroups when the caller asks for them here
+// (unsynchronised single-shard steps: one launch of ~8 us less per step); n_split = 0: not wanted.
+struct TreeSplitReq { int n_split = 0; int* first = nullptr; int* n_anc = nullptr; int* anc = nullptr; int max_anc = 0; const int* info = nullptr; int* poison = nullptr; };
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
-                        int* out_info, TreeDevWork* work, int want_hot = 0 /* fill NodeB::hot (LDS-staged walk only) */);
+                        int* out_info, TreeDevWork* work, int want_hot = 0 /* fill NodeB::hot (LDS-staged walk only) */, const TreeSplitReq* split = nullptr);
 // level-order copy of a pre-order node array for the cooperative block walk
 size_t bfs_workspace_bytes(size_t n_cap);
 int build_bfs_layout(hipStream_t s, const float4* nodes, int n_nodes, void* workspace, size_t n_cap, float4* out);
@@ -212,7 +215,7 @@ int build_octree_device_f64(hipStream_t s, const double4* pos, const int* d_coun
 int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
                    void* workspace, size_t n_cap, int* out_info, TreeDevWork* work);
 int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
-                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge);
+                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge, const TreeSplitReq* split = nullptr);
 // the two halves of tree_emit_sorted, for the spatial-shard build (the nodes are emitted after an exchange, at an offset
 // in the global-index array, with each node's parent and depth)
 int tree_scan_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info,

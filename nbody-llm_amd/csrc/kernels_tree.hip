@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256) void k_tree_big_groups(const P4* __restrict__ 
     if (n_big > 0) sort_big_groups(pos, cx0, cy0, cz0, width, keys, keys2, ids, flags, kMaxTie, big_list, n_big);
 }
 
+__device__ __forceinline__ void split_anc_block(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
+                                                const signed char* __restrict__ delta, const int* __restrict__ base, int n, int n_nodes, int n_split,
+                                                int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc,
+                                                const int* __restrict__ info, int* __restrict__ poison, int node_cap, const int s, const int a);
+
 // One thread per NODE (not per body: the first body of a big cell opens every level above it, and 15
 // cells x a 17-step binary search in one thread was the kernel's whole duration, 30 us).  Node idx
 // belongs to the body k with base[k] <= idx < base[k+1] (binary search); its t-th node is the cell of
@@ -235,7 +240,14 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
                                                    Real width, NodeT* __restrict__ nodes, int node_cap,
                                                    int* __restrict__ order, int* __restrict__ out_info, int want_hot,
                                                    const int* __restrict__ edge, const int* __restrict__ node_offset,
-                                                   int* __restrict__ parent_out, unsigned char* __restrict__ depth_out) {
+                                                   int* __restrict__ parent_out, unsigned char* __restrict__ depth_out,
+                                                   TreeSplitReq split, int emit_blocks) {
+    if (int(blockIdx.x) >= emit_blocks) {   // the walk's split points, one workgroup each, in the same launch (they need the scans' results only)
+        if (threadIdx.x < 64)
+            split_anc_block(keys, keys2, delta, base, *count, node_cap, split.n_split, split.first, split.n_anc, split.anc, split.max_anc, split.info,
+                            split.poison, node_cap, int(blockIdx.x) - emit_blocks, threadIdx.x);
+        return;
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
     // spatial shards: the slice goes straight to its place in the global-index array (indices and links shifted)
@@ -348,13 +360,14 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
 // ancestors of the node-range split points (the walk's WalkSplit lists), root first.  Node t lies in
 // the run emitted by body k (base[k] <= t); its ancestors are the cells of depths 0 .. depth(t)-1 on
 // that body's path, each opened by the first sorted body that shares the prefix.
-__global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
-                                 const signed char* __restrict__ delta,
-                                 const int* __restrict__ base, int n, int n_nodes, int n_split,
-                                 int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc,
-                                 const int* __restrict__ info, int* __restrict__ poison) {
-    const int s = blockIdx.x;
-    const int a = threadIdx.x;  // candidate ancestor depth
+__device__ __forceinline__ void split_anc_block(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
+                                                const signed char* __restrict__ delta, const int* __restrict__ base, int n, int n_nodes, int n_split,
+                                                int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc,
+                                                const int* __restrict__ info, int* __restrict__ poison, int node_cap, const int s, const int a) {
+    if (info && node_cap >= 0 && info[1] == 0 && info[0] > node_cap) {   // (riding in the emit's launch: its own "node array too small" may not be visible yet)
+        if (poison && s == 0 && a == 0) atomicOr(poison, 2);
+        return;
+    }
     if (info) {   // unsynchronised step: the host has not seen this build's result
         if (info[1] != 0) {   // the build needs the host (too deep / node array too small): stop everything that follows
             if (poison && s == 0 && a == 0) atomicOr(poison, info[1]);
@@ -398,6 +411,13 @@ __global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, co
     const int kf = l2;
     const int dp = (kf > 0) ? delta[kf - 1] : -1;
     anc[s * max_anc + a] = base[kf] + (a - (dp + 1));
+}
+__global__ void k_tree_split_anc(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
+                                 const signed char* __restrict__ delta,
+                                 const int* __restrict__ base, int n, int n_nodes, int n_split,
+                                 int* __restrict__ first, int* __restrict__ n_anc, int* __restrict__ anc, int max_anc,
+                                 const int* __restrict__ info, int* __restrict__ poison) {
+    split_anc_block(keys, keys2, delta, base, n, n_nodes, n_split, first, n_anc, anc, max_anc, info, poison, -1, blockIdx.x, threadIdx.x);
 }
 
 // ---- the two scans of the build in three launches with a FIXED association order: per body k the exclusive
@@ -647,12 +667,15 @@ int scan_sorted_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper,
 template <class P4, class Real, class NodeT>
 int emit_nodes_t(hipStream_t s, const P4* pos, const int* d_count, Real width, void* workspace, size_t n_cap, NodeT* nodes, int node_cap,
                  int slice_cap, int* order, int* out_info, int want_hot, const int* edge, const int* node_offset, int* parent,
-                 unsigned char* depth) {
+                 unsigned char* depth, const TreeSplitReq* split = nullptr) {
     const BuildLayout L = build_layout(workspace, n_cap);
     // one thread per node; their number is known on the device only, so one per node the slice can have
     // (threads beyond the tree leave at once; a tree beyond the array sets flag 2 and the caller grows it)
-    hipLaunchKernelGGL((k_tree_emit<P4, Real, NodeT>), dim3((std::max(1, slice_cap) + 255) / 256), dim3(256), 0, s, L.keys, L.keys2, L.ids, pos,
-                       d_count, L.delta, L.base, L.incl, width, nodes, node_cap, order, out_info, want_hot, edge, node_offset, parent, depth);
+    const int emit_blocks = (std::max(1, slice_cap) + 255) / 256;
+    const TreeSplitReq req = split ? *split : TreeSplitReq{};
+    hipLaunchKernelGGL((k_tree_emit<P4, Real, NodeT>), dim3(emit_blocks + req.n_split), dim3(256), 0, s, L.keys, L.keys2, L.ids, pos,
+                       d_count, L.delta, L.base, L.incl, width, nodes, node_cap, order, out_info, want_hot, edge, node_offset, parent, depth, req,
+                       emit_blocks);
     return 0;
 }
 }  // namespace
@@ -680,19 +703,20 @@ int tree_emit_nodes(hipStream_t s, const float4* pos, const int* d_count, int n_
                                                node_offset, parent, depth);
 }
 int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
-                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge) {
+                     float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge, const TreeSplitReq* split) {
     if (tree_scan_sorted(s, pos, d_count, n_upper, workspace, n_cap, out_info, edge) != 0) return -1;
-    return tree_emit_nodes(s, pos, d_count, n_upper, width, workspace, n_cap, nodes, node_cap, node_cap, order, out_info, want_hot, edge,
-                           nullptr, nullptr, nullptr);
+    (void)n_upper;
+    return emit_nodes_t<float4, float, float4>(s, pos, d_count, width, workspace, n_cap, nodes, node_cap, node_cap, order, out_info, want_hot, edge,
+                                               nullptr, nullptr, nullptr, split);
 }
 
 // Enqueues the whole build on `s`.  out_info (device, 3 ints): [0] = node count, [1] = flags, [2] = bodies in the tree
 // (1: deeper than 42 levels, 2: node_cap too small).  The caller reads it back before the walk.
 int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3],
                         float width, void* workspace, size_t n_cap, float4* nodes, int node_cap, int* order,
-                        int* out_info, TreeDevWork* work, int want_hot) {
+                        int* out_info, TreeDevWork* work, int want_hot, const TreeSplitReq* split) {
     if (tree_sort_keys(s, pos, d_count, n_upper, center, width, workspace, n_cap, out_info, work) != 0) return -1;
-    return tree_emit_sorted(s, pos, d_count, n_upper, width, workspace, n_cap, nodes, node_cap, order, out_info, want_hot, nullptr);
+    return tree_emit_sorted(s, pos, d_count, n_upper, width, workspace, n_cap, nodes, node_cap, order, out_info, want_hot, nullptr, split);
 }
 // The same for F = f64: keys from the reference's recurrences in double, centres of mass from the same f64 prefix sums
 // (against the reference's sequential f64 folds they differ in the last bits only), 64-byte node records.

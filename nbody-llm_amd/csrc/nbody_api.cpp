@@ -776,14 +776,6 @@ int bh_walk_device_tree_async(NbodyHandle* h) {
     int rc = ensure_tree_dev(h, std::max<size_t>(h->d_node_cap, 4 * n_upper + 64), n_upper);
     if (rc) return rc;
     if (h->pending.empty()) HIP_TRY(h, hipMemsetAsync(h->d_poison + 1, 0, sizeof(int), h->stream));   // steps completed: counted from here
-    nbody::TreeDevWork work;
-    if (nbody::build_octree_device(h->stream, sh.own_pos(), sh.own_count(), int(n_upper), h->center, h->width, h->d_tree_ws, n_cap,
-                                   h->d_nodes, int(h->d_node_cap), h->d_order, h->d_tree_info, &work, 0) != 0)
-        return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
-    HIP_TRY(h, hipGetLastError());
-    h->stats.tree_build_ms += ms_since(t1);   // (enqueue time: nothing is waited for)
-    h->tree_on_device = true;
-
     constexpr int kMaxSplit = 64, kMaxAnc = 192;
     if (!h->d_split) {
         HIP_TRY(h, hipMalloc(&h->d_split, (kMaxSplit + 1 + kMaxSplit + kMaxSplit * kMaxAnc) * sizeof(int)));
@@ -793,6 +785,17 @@ int bh_walk_device_tree_async(NbodyHandle* h) {
     if (h->cfg.math_mode == NBODY_MATH_STRICT && nbody::tuning().bh_walk_split <= 0) K = 1;  // parity path: the reference's sum order
     while (nbody::tuning().bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > n_upper) K /= 2;   // (a tree has at least as many nodes as bodies)
     if (n_upper == 0) K = 1;
+    // the walk's split points ride in the build's last launch (they also make a build that needs the host sticky: Shard::poison)
+    nbody::TreeSplitReq req;
+    req.n_split = K; req.first = h->d_split; req.n_anc = h->d_split + kMaxSplit + 1; req.anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
+    req.max_anc = kMaxAnc; req.info = h->d_tree_info; req.poison = h->d_poison;
+    nbody::TreeDevWork work;
+    if (nbody::build_octree_device(h->stream, sh.own_pos(), sh.own_count(), int(n_upper), h->center, h->width, h->d_tree_ws, n_cap,
+                                   h->d_nodes, int(h->d_node_cap), h->d_order, h->d_tree_info, &work, 0, n_upper > 0 ? &req : nullptr) != 0)
+        return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
+    HIP_TRY(h, hipGetLastError());
+    h->stats.tree_build_ms += ms_since(t1);   // (enqueue time: nothing is waited for)
+    h->tree_on_device = true;
     nbody::TreeDev td;
     td.nodes = h->d_nodes; td.n_nodes = int(h->d_node_cap);   // (the plain walks end at the split points, not at n_nodes)
     td.order = h->d_order; td.n_order = int(n_upper);
@@ -802,8 +805,9 @@ int bh_walk_device_tree_async(NbodyHandle* h) {
     td.split_first = h->d_split;
     td.split_n_anc = h->d_split + kMaxSplit + 1;
     td.split_anc = h->d_split + kMaxSplit + 1 + kMaxSplit;
-    nbody::launch_tree_split_anc(h->stream, work, int(n_upper), int(h->d_node_cap), K, h->d_split, h->d_split + kMaxSplit + 1,
-                                 h->d_split + kMaxSplit + 1 + kMaxSplit, kMaxAnc, h->d_tree_info, h->d_poison);
+    if (n_upper == 0)   // (no build was enqueued: the empty root's one segment, as a launch of its own)
+        nbody::launch_tree_split_anc(h->stream, work, int(n_upper), int(h->d_node_cap), K, h->d_split, h->d_split + kMaxSplit + 1,
+                                     h->d_split + kMaxSplit + 1 + kMaxSplit, kMaxAnc, h->d_tree_info, h->d_poison);
     if (K > 1) {
         const size_t need = size_t(K) * sh.seg_cap;
         if (need > h->walk_planes_cap) {
