@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_tree_keys(const P4* __restrict__ pos, c
                                                    unsigned long long* __restrict__ keys, int* __restrict__ ids,
                                                    int* __restrict__ out_info, int* __restrict__ counters) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k == 0) { out_info[0] = 0; out_info[1] = 0; counters[0] = 0; }  // node count and flags of this build; k_tree_ties' list length (first kernel of the build)
+    if (k == 0) { out_info[0] = 0; out_info[1] = 0; }  // node count and flags of this build (first kernel of the build)
     if (k >= n_upper) return;
     if (k >= *count) {  // n_upper only bounds the live count: the unused tail sorts to the end (bit 63 set),
         keys[k] = ~0ull;  // where every later kernel ignores it (they all read *count)
@@ -110,15 +110,14 @@ __device__ __forceinline__ int common_levels2(const unsigned long long* __restri
 // (insertion sort; the radix sort is stable, so equal keys keep ascending ids), and inside it every run of equal FULL
 // keys gets its second keys (levels 21..41) and is put in their order.  Groups are pairs in practice.  A group of more
 // than kMaxLowGroup bodies (a dense clump inside one level-16 cell, 1e-3 of a width-64 box) is not sorted by one thread:
-// its bounds go on a list and k_tree_big_groups sorts it (sort_big_groups: up to kMaxBigGroup bodies,
-// kMaxBigGroups groups per build).  Beyond that -- and for a run of more than tuning().tree_max_tie (64) equal FULL keys -- the build
+// the workgroup its leader sits in sorts it together (sort_big_group: up to kMaxBigGroup bodies, kBigPerBlock such groups per
+// workgroup).  Beyond that -- and for a run of more than tuning().tree_max_tie (64) equal FULL keys -- the build
 // raises a flag: 1 = "deeper than the build's 42 levels", 4 = "a clump larger than the build sorts" (the single-GPU step
 // then builds on the host; a spatial rank reports it as what it is).
 constexpr int kSortLowBits = 15;    // key bits the radix sort leaves to k_tree_ties (levels 16..20)
 constexpr int kMaxLowGroup = 256;
 constexpr int kBigItems = 16;
 constexpr int kMaxBigGroup = 256 * kBigItems;   // 4096 bodies: one workgroup's block_radix_sort
-constexpr int kMaxBigGroups = 256;              // list entries {begin, end}
 
 // runs of equal FULL keys inside the sorted group [a0, e): second keys (levels 21..41), put in their order
 template <class P4, class Real>
@@ -142,44 +141,54 @@ __device__ void finish_equal_key_runs(const P4* __restrict__ pos, Real cx0, Real
     }
 }
 
-// the listed groups (257 .. 4096 bodies sharing 16 levels), one after the other by ONE workgroup (k_tree_big_groups; the
-// list is empty in all but pathological worlds): a stable block radix
-// sort on the 15 low key bits (the group's top bits are equal), then the runs of equal full keys as above
+// A big group (257 .. 4096 bodies sharing 16 levels) is sorted by the WORKGROUP its leader sits in: a stable block radix
+// sort of {15 low key bits, place in the group} pairs (16 KB of LDS: the 8-byte keys stay in global memory and are
+// gathered into their new places afterwards), then the runs of equal full keys as above.
 template <class P4, class Real>
-__device__ void sort_big_groups(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width, unsigned long long* __restrict__ keys,
-                                unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags, int kMaxTie,
-                                const int* __restrict__ big_list, int n_groups) {
-    using Sort = rocprim::block_radix_sort<unsigned long long, 256, kBigItems, int>;
+__device__ void sort_big_group(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width, unsigned long long* __restrict__ keys,
+                               unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags, int kMaxTie, int b, int e) {
+    using Sort = rocprim::block_radix_sort<unsigned short, 256, kBigItems, unsigned short>;
     __shared__ typename Sort::storage_type storage;
-    for (int g = 0; g < n_groups; ++g) {
-        const int b = big_list[2 * g], e = big_list[2 * g + 1];
-        unsigned long long k[kBigItems];
-        int v[kBigItems];
+    unsigned short k[kBigItems], v[kBigItems];
 #pragma unroll
-        for (int i = 0; i < kBigItems; ++i) {
-            const int q = b + int(threadIdx.x) * kBigItems + i;
-            k[i] = q < e ? keys[q] : ~0ull;     // (the padding sorts behind everything: the sort is stable and it comes last)
-            v[i] = q < e ? ids[q] : -1;
-        }
-        __syncthreads();
-        Sort().sort(k, v, storage, 0, kSortLowBits);
-#pragma unroll
-        for (int i = 0; i < kBigItems; ++i) {
-            const int q = b + int(threadIdx.x) * kBigItems + i;
-            if (q < e) { keys[q] = k[i]; ids[q] = v[i]; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, b, e, flags, kMaxTie);
-        __syncthreads();
+    for (int i = 0; i < kBigItems; ++i) {
+        const int q = b + int(threadIdx.x) * kBigItems + i;
+        k[i] = q < e ? (unsigned short)(keys[q] & ((1ull << kSortLowBits) - 1ull)) : (unsigned short)0xffff;   // (the padding sorts behind everything)
+        v[i] = q < e ? (unsigned short)(int(threadIdx.x) * kBigItems + i) : (unsigned short)0xffff;
     }
+    __syncthreads();
+    Sort().sort(k, v, storage, 0, 16);
+    unsigned long long kk[kBigItems];
+    int ii[kBigItems];
+#pragma unroll
+    for (int i = 0; i < kBigItems; ++i) {
+        const bool live = v[i] != (unsigned short)0xffff;
+        kk[i] = live ? keys[b + v[i]] : 0ull;
+        ii[i] = live ? ids[b + v[i]] : 0;
+    }
+    __syncthreads();   // (everybody has read its sources before anybody writes)
+#pragma unroll
+    for (int i = 0; i < kBigItems; ++i) {
+        const int q = b + int(threadIdx.x) * kBigItems + i;
+        if (q < e) { keys[q] = kk[i]; ids[q] = ii[i]; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, b, e, flags, kMaxTie);
+    __syncthreads();
 }
+
+constexpr int kBigPerBlock = 8;   // big groups one workgroup of k_tree_ties can lead
 
 template <class P4, class Real>
 __global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, const int* __restrict__ count, Real cx0, Real cy0,
                                                    Real cz0, Real width, unsigned long long* __restrict__ keys,
                                                    unsigned long long* __restrict__ keys2, int* __restrict__ ids, int* __restrict__ flags,
-                                                   int kMaxTie, int* __restrict__ big_list /* {begin, end} pairs */,
-                                                   int* __restrict__ counters /* [0] pairs listed */) {
+                                                   int kMaxTie) {
+    __shared__ int big[2 * kBigPerBlock];
+    __shared__ int n_big;
+    if (threadIdx.x == 0) n_big = 0;
+    __syncthreads();
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
     bool leader = j + 1 < n;
@@ -194,9 +203,9 @@ __global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, c
         if (e - j > kMaxLowGroup) {
             if (e - j > kMaxBigGroup) atomicOr(flags, 4);
             else {
-                const int slot = atomicAdd(&counters[0], 1);
-                if (slot >= kMaxBigGroups) atomicOr(flags, 4);
-                else { big_list[2 * slot] = j; big_list[2 * slot + 1] = e; }
+                const int slot = atomicAdd(&n_big, 1);
+                if (slot >= kBigPerBlock) atomicOr(flags, 4);
+                else { big[2 * slot] = j; big[2 * slot + 1] = e; }
             }
         } else {
             for (int q = j + 1; q < e; ++q) {           // by the full key
@@ -209,18 +218,9 @@ __global__ __launch_bounds__(256) void k_tree_ties(const P4* __restrict__ pos, c
             finish_equal_key_runs(pos, cx0, cy0, cz0, width, keys, keys2, ids, j, e, flags, kMaxTie);
         }
     }
-}
-
-// The listed groups, by one workgroup in a launch of its own.  (Round 3 first let the LAST workgroup of k_tree_ties do it --
-// "last one in" needs a device-scope fence in every workgroup, and with the sort's 50 KB of LDS in the kernel that made
-// k_tree_ties 17 us instead of 4.7 at 65 536 bodies and 1 ms at 4 M: a 4.7 us launch is the cheaper way to wait for a grid.)
-template <class P4, class Real>
-__global__ __launch_bounds__(256) void k_tree_big_groups(const P4* __restrict__ pos, Real cx0, Real cy0, Real cz0, Real width,
-                                                         unsigned long long* __restrict__ keys, unsigned long long* __restrict__ keys2,
-                                                         int* __restrict__ ids, int* __restrict__ flags, int kMaxTie,
-                                                         const int* __restrict__ big_list, const int* __restrict__ counters) {
-    const int n_big = min(counters[0], kMaxBigGroups);
-    if (n_big > 0) sort_big_groups(pos, cx0, cy0, cz0, width, keys, keys2, ids, flags, kMaxTie, big_list, n_big);
+    __syncthreads();
+    const int todo = min(n_big, kBigPerBlock);   // (uniform: every thread of the workgroup takes part in the sorts)
+    for (int g = 0; g < todo; ++g) sort_big_group(pos, cx0, cy0, cz0, width, keys, keys2, ids, flags, kMaxTie, big[2 * g], big[2 * g + 1]);
 }
 
 __device__ __forceinline__ void split_anc_block(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
@@ -643,11 +643,8 @@ int sort_keys_t(hipStream_t s, const P4* pos, const int* d_count, int n_upper, c
     // (bits [15, 63): the unused tail's keys are all ones and stay behind every real body -- the sort is stable and the
     // tail comes last in the input; k_tree_ties finishes the low bits)
     if (rocprim::radix_sort_pairs(L.tmp, tb, L.keys_in, L.keys, L.ids_in, L.ids, size_t(n), kSortLowBits, 63, s) != hipSuccess) return -1;
-    int* big_list = static_cast<int*>(L.tmp);   // (the sort is done with its scratch; the scans take it over after this)
     hipLaunchKernelGGL((k_tree_ties<P4, Real>), dim3((n + 255) / 256), dim3(256), 0, s, pos, d_count, center[0], center[1], center[2], width,
-                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie), big_list, L.counters);
-    hipLaunchKernelGGL((k_tree_big_groups<P4, Real>), dim3(1), dim3(256), 0, s, pos, center[0], center[1], center[2], width, L.keys, L.keys2, L.ids,
-                       out_info + 1, std::max(1, tuning().tree_max_tie), big_list, L.counters);
+                       L.keys, L.keys2, L.ids, out_info + 1, std::max(1, tuning().tree_max_tie));
     return 0;
 }
 template <class P4>
