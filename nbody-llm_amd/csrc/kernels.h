@@ -16,6 +16,7 @@ struct Tuning {
     int bf_fast_variant = 0;    // 0: symmetric kernels where they apply, 1..: the LDS-tiled one-sided forms (kernels_bf.hip)       [NBODY_BF_VARIANT]
     int bh_walk_duo = -1;       // Barnes-Hut fast walk: bodies of the tree order per lane sharing their node fetches (k_bh_walk_duo):
                                 // -1 from the body count (walk_plan), 0 / 1 one body per lane (k_bh_walk), 2 3 4 6 8                              [NBODY_BH_DUO]
+    int bh_walk_xcd = 1;        // k_bh_walk_duo / k_bh_walk_fast64: each XCD walks one eighth of the tree order (its L2 then holds that region's deep nodes)  [NBODY_BH_XCD]
     int let_list_div = 4;       // spatial shards: export / import buffers start at (slice node capacity) / this (they grow when a step needs more)
     int sym_wpb = 4;            // k_bf_sym: waves per workgroup: 4 (default), 8, 12 or 16                                           [NBODY_SYM_WPB]
     int sym_rounds = 1;         // k_bf_sym: rounds of workgroups per CU

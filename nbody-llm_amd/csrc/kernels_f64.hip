@@ -5,6 +5,7 @@
 // k_bh_walk_nested / k_bh_walk<false, DIRECT>) with double4 state and 64-byte node records.
 // Compiled with -ffp-contract=off; f64 sqrt and divide are correctly rounded on gfx950.
 #include "kernels_f64.h"
+#include "kernels.h"   // nbody::tuning()
 
 #include <algorithm>
 
@@ -317,11 +318,13 @@ __device__ __forceinline__ int walk_entry64(const Node64* __restrict__ nodes, co
 template <bool DIRECT, int BPL>
 __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_fast64(const Node64* __restrict__ nodes, int n_nodes, const int* __restrict__ order, int n_order,
                                                                const double4* __restrict__ pos, double4* __restrict__ acc, double g, double eps2,
-                                                               double theta2, unsigned long long* __restrict__ counters, WalkSplit64 split) {
-    const int t = blockIdx.x * kWalkBlock + threadIdx.x;
+                                                               double theta2, unsigned long long* __restrict__ counters, WalkSplit64 split, int xcd_blocks) {
+    // (xcd_blocks != 0: XCD j -- workgroups j, j + 8, ... -- walks the j-th eighth of the tree order: kernels_bh.hip k_bh_walk_duo)
+    const int bx = xcd_blocks ? int(blockIdx.x % 8) * xcd_blocks + int(blockIdx.x / 8) : int(blockIdx.x);
+    const int t = bx * kWalkBlock + threadIdx.x;
     // a body group's long walks are in the segments around its own place in the tree: those first (kernels_bh.hip k_bh_walk)
     const int K = gridDim.y;
-    const int diag = int((long long)blockIdx.x * K / gridDim.x);
+    const int diag = int((long long)bx * K / gridDim.x);
     const int kk = blockIdx.y;
     const int seg = ((diag + ((kk & 1) ? (kk + 1) / 2 : -(kk / 2))) % K + K) % K;
     const int s1 = split.first[seg + 1];
@@ -468,8 +471,10 @@ void launch_bh_walk_fast(hipStream_t s, const Dev& d, const Node64* nodes, int n
                          double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split, int bodies_per_lane) {
     if (n_order <= 0) return;
     const int bpl = bodies_per_lane >= 6 ? 6 : bodies_per_lane >= 4 ? 4 : bodies_per_lane == 3 ? 3 : bodies_per_lane == 2 ? 2 : 1;
-    const dim3 grid(blocks_for((n_order + bpl - 1) / bpl, kWalkBlock), split.n_seg);
-#define WALK64(D, B) hipLaunchKernelGGL((k_bh_walk_fast64<D, B>), grid, dim3(kWalkBlock), 0, s, nodes, n_nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters, split)
+    const int gx = int(blocks_for((n_order + bpl - 1) / bpl, kWalkBlock)), gx8 = (gx + 7) / 8 * 8;
+    const int xcd_blocks = nbody::tuning().bh_walk_xcd ? gx8 / 8 : 0;
+    const dim3 grid(xcd_blocks ? gx8 : gx, split.n_seg);
+#define WALK64(D, B) hipLaunchKernelGGL((k_bh_walk_fast64<D, B>), grid, dim3(kWalkBlock), 0, s, nodes, n_nodes, order, n_order, d.pos, d.acc, g, eps2, theta2, counters, split, xcd_blocks)
 #define WALK64_B(D) do { if (bpl == 6) WALK64(D, 6); else if (bpl == 4) WALK64(D, 4); else if (bpl == 3) WALK64(D, 3); else if (bpl == 2) WALK64(D, 2); else WALK64(D, 1); } while (0)
     if (leaf_direct) WALK64_B(true); else WALK64_B(false);
 #undef WALK64_B

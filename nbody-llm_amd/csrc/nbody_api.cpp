@@ -1157,7 +1157,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
         nbody::Tuning& t = h->tune;
         const struct { const char* env; int* knob; } table[] = {
             {"NBODY_BF_VARIANT", &t.bf_fast_variant}, {"NBODY_CROSS_SYM", &t.cross_sym}, {"NBODY_SYM_PACKED", &t.sym_packed},
-            {"NBODY_BH_SPLIT", &t.bh_walk_split}, {"NBODY_SYM_WPB", &t.sym_wpb}, {"NBODY_BH_DUO", &t.bh_walk_duo},
+            {"NBODY_BH_SPLIT", &t.bh_walk_split}, {"NBODY_SYM_WPB", &t.sym_wpb}, {"NBODY_BH_DUO", &t.bh_walk_duo}, {"NBODY_BH_XCD", &t.bh_walk_xcd},
 #ifdef NBODY_TUNING
             {"NBODY_BH_VARIANT", &t.bh_walk_variant}, {"NBODY_BH_HOT", &t.bh_hot_cap}, {"NBODY_BH_LDS_BLOCK", &t.bh_walk_lds_block},
 #endif
@@ -1789,7 +1789,7 @@ namespace {
 struct Knob { const char* name; int nbody::Tuning::*field; bool tuning_build_only; };
 const Knob kKnobs[] = {
     {"cross_sym", &nbody::Tuning::cross_sym, false}, {"sym_packed", &nbody::Tuning::sym_packed, false},
-    {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false}, {"let_list_div", &nbody::Tuning::let_list_div, false}, {"bh_walk_duo", &nbody::Tuning::bh_walk_duo, false},
+    {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false}, {"let_list_div", &nbody::Tuning::let_list_div, false}, {"bh_walk_duo", &nbody::Tuning::bh_walk_duo, false}, {"bh_walk_xcd", &nbody::Tuning::bh_walk_xcd, false},
     {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_k", &nbody::Tuning::sym_k, false},
     {"sym_min_bodies", &nbody::Tuning::sym_min_bodies, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
     {"cross_slots", &nbody::Tuning::cross_slots, false}, {"cross_ipt", &nbody::Tuning::cross_ipt, false},
