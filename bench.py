@@ -181,7 +181,7 @@ def bf_roofline(args, world, n, kernel_ms, launches, k_inter):
     return r
 
 
-def bh_roofline(n_local, kernel_ms, launches, visits_per_launch, tree):
+def bh_roofline(n_local, kernel_ms, launches, visits_per_launch, tree, math="fast"):
     """The walk: L1/TA bound.  achieved = L1 cache-line accesses per cycle per CU = this run's
     opening tests (one 32-byte node record each, two 16-byte gathers) per cycle per CU, from its visit count and
     HIP-event kernel time, x the L1 line accesses per visit of the PMC pass kept in profiles/ (TCP_TOTAL_CACHE_ACCESSES
@@ -200,7 +200,7 @@ def bh_roofline(n_local, kernel_ms, launches, visits_per_launch, tree):
     lines = per_visit * vpc if per_visit else None
     rows = ceil.get("by_lanes_per_record_visits_per_cycle_per_cu") or {}
     return {
-        "bound": "l1-ta", "kernel": (pj.get("kernel") or "k_bh_walk") + " (+ k_bh_reduce)", "achieved": lines, "peak": peak_lines,
+        "bound": "l1-ta", "kernel": ((pj.get("kernel") or "k_bh_walk") + " (+ k_bh_reduce)") if math == "fast" else "k_bh_walk_nested (strict: the reference's nested sums, one segment; the L1 figures below are the fast walk's)", "achieved": lines, "peak": peak_lines,
         "unit": "L1 cache-line accesses/cycle/CU", "frac": (lines / peak_lines) if (lines and peak_lines) else None,
         "traffic": traffic,
         "note": "since round 3 a lane walks several neighbouring bodies and fetches the union of their node sequences once: "
@@ -314,7 +314,7 @@ def bh_record(args, n, tree, elapsed, stats):
             "tree_copy": stats.tree_copy_ms / args.steps,       # host build only: D2H positions + H2D nodes (incl. waiting for the previous step)
             "walk_kernel": stats.force_kernel_ms / max(1.0, launches),
         },
-        "roofline": bh_roofline(n, stats.force_kernel_ms, launches, visits / max(1, args.steps), tree),   # (one walk launch per step)
+        "roofline": bh_roofline(n, stats.force_kernel_ms, launches, visits / max(1, args.steps), tree, args.math),   # (one walk launch per step)
         "parity": PARITY[("bh", args.math)],
     }
     return rec
@@ -413,7 +413,7 @@ def main():
         if args.workload == "bf":
             roofline = bf_roofline(args, world, n, kernel_ms, launches, k_inter)
         else:
-            roofline = bh_roofline(n / world, kernel_ms, launches, (visits / world) / max(1, args.steps), args.tree)
+            roofline = bh_roofline(n / world, kernel_ms, launches, (visits / world) / max(1, args.steps), args.tree, args.math)
         result = {
             "metric": "pairwise_interactions_per_sec", "value": value, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
