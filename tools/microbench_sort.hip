@@ -43,6 +43,8 @@ int main() {
         hipMemcpy(vin, hv.data(), n * 4, hipMemcpyHostToDevice);
         printf("n = %zu\n", n);
         run<rocprim::default_config>("default", n, kin, kout, vin, vout, 15);
+        run<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>>("tuned onesweep (merge limit 0)", n, kin, kout, vin, vout, 15);
+        run<rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>>("tuned onesweep, 32 bits", n, kin, kout, vin, vout, 31);
         run<OS<8>>("onesweep 8 bits", n, kin, kout, vin, vout, 15);
         run<OS<6>>("onesweep 6 bits", n, kin, kout, vin, vout, 15);
         run<OS<7>>("onesweep 7 bits", n, kin, kout, vin, vout, 15);
