@@ -194,6 +194,28 @@ def test_several_bodies_per_lane_walk_exactly_like_one(gpu, orc, n, split, leaf,
             assert out[2][1] == orc.bh_update_forces(ref, sd, box[0], box[1], threads=4)
 
 
+@pytest.mark.parametrize("f64", [False, True])
+def test_xcd_aware_lane_groups_change_nothing_but_the_order_of_work(gpu, f64):
+    """bh_walk_xcd (default on): XCD j walks the j-th eighth of the tree order instead of every eighth lane group.  Which
+    workgroup walks which bodies does not enter any sum: bit-identical accelerations and equal counts, also when the
+    number of lane groups is not a multiple of eight."""
+    nb = gpu
+    _, st = sd_st(nb, theta2=0.25, g_soft=0.01)
+    for n in (30011, 70000):
+        ics = nb.plummer(n, seed=38, f64=f64)
+        out = []
+        for xcd in (0, 1):
+            with nb.Simulation(ics, *BOX, method=nb.BARNES_HUT, math_mode=nb.FAST, tree_build=nb.TREE_DEVICE, tuning=dict(bh_walk_xcd=xcd)) as sim:
+                sim.settings = st
+                sim.steps(2)
+                s = sim.stats()
+                out.append((sim.get_points(), s.interactions, s.node_visits))
+        word = np.uint64 if f64 else np.uint32
+        assert out[0][1:] == out[1][1:]
+        for f in ("position", "velocity", "acceleration"):
+            assert np.array_equal(out[0][0][f].view(word), out[1][0][f].view(word)), (n, f)
+
+
 def test_retain_in_a_tight_box(gpu, orc):
     nb = gpu
     box = ((0.0, 0.0, 0.0), 2.0)
