@@ -80,7 +80,8 @@ enum { NBODY_F32 = 0,  /* PointParticle<f32,3>: every path of this library */
                           the same templated restatement); with NBODY_TREE_DEVICE the tree is built on the device (same cells, centres
                           of mass to the last bits: node counts within 1e-6), ~4x the steps per second.  NBODY_MATH_FAST: one running
                           sum per lane (FMA, 1/sqrt) over a split node range, device build under AUTO: accelerations to 1e-12.
-                          Worlds of several ranks: index-block shards (strict results bit-equal to one shard), tree built on the host */
+                          Worlds of several ranks: index-block shards (strict results bit-equal to one shard; the tree is built on the
+                          host in strict math, by every rank on the device from the gathered positions in fast math) */
 
 /* how the bodies are dealt to the shards of a multi-GPU run */
 enum { NBODY_SHARD_INDEX = 0,   /* contiguous index blocks of the vector; positions all-gathered every step (every method) */

@@ -195,6 +195,10 @@ size_t tree_build_tmp_bytes(size_t n_cap);
 size_t tree_cat_bytes(size_t n_cap);
 TreeCat tree_cat_layout(void* buf, size_t n_cap);
 void launch_tree_cat(hipStream_t s, const Shard& sh, const TreeCat& c);
+// the same for F = f64 (double4 positions; the TreeCat's pos is unused)
+size_t tree_cat_bytes64(size_t n_cap);
+TreeCat tree_cat_layout64(void* buf, size_t n_cap, double4** pos_cat);
+void launch_tree_cat64(hipStream_t s, const double4* pos_all, const int* seg_count, int n_seg, int seg_cap, int my_seg, double4* pos_cat, int* info);
 int launch_tree_own_order(hipStream_t s, const int* order, const TreeCat& c, int n_total_upper, void* tmp, size_t tmp_bytes);
 // The walk's node-range split points ride in the emit's launch as extra workgroups when the caller asks for them here
 // (unsynchronised single-shard steps: one launch of ~8 us less per step); n_split = 0: not wanted.

@@ -573,6 +573,22 @@ __global__ __launch_bounds__(256) void k_tree_cat(const float4* __restrict__ pos
     if (j < seg_count[sgm]) pos_cat[first + j] = pos_all[size_t(sgm) * seg_cap + j];
 }
 
+__global__ __launch_bounds__(256) void k_tree_cat64(const double4* __restrict__ pos_all, const int* __restrict__ seg_count,
+                                                    int n_seg, int seg_cap, int my_seg, double4* __restrict__ pos_cat,
+                                                    int* __restrict__ info) {   // (k_tree_cat for F = f64)
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int sgm = idx / seg_cap, j = idx - sgm * seg_cap;
+    if (sgm >= n_seg) return;
+    int first = 0, own_first = 0, total = 0;
+    for (int t = 0; t < n_seg; ++t) {
+        if (t == sgm) first = total;
+        if (t == my_seg) own_first = total;
+        total += seg_count[t];
+    }
+    if (idx == 0) { info[0] = total; info[1] = own_first; info[2] = seg_count[my_seg]; }
+    if (j < seg_count[sgm]) pos_cat[first + j] = pos_all[size_t(sgm) * seg_cap + j];
+}
+
 // tree-order list of all bodies -> flags of the own ones
 __global__ __launch_bounds__(256) void k_tree_own_flags(const int* __restrict__ order, const int* __restrict__ info,
                                                         int* __restrict__ flags) {
@@ -828,6 +844,28 @@ TreeCat tree_cat_layout(void* buf, size_t n_cap) {
     c.own_order = reinterpret_cast<int*>(p); p += al(n_cap * 4);
     c.info = reinterpret_cast<int*>(p);
     return c;
+}
+
+// F = f64: the side buffer holds double4 positions (tree_cat_bytes64); flags / base / own_order / info as in TreeCat (pos unused)
+size_t tree_cat_bytes64(size_t n_cap) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    return al(n_cap * sizeof(double4)) + 3 * al(n_cap * 4) + 256;
+}
+TreeCat tree_cat_layout64(void* buf, size_t n_cap, double4** pos_cat) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    char* p = static_cast<char*>(buf);
+    TreeCat c;
+    *pos_cat = reinterpret_cast<double4*>(p); p += al(n_cap * sizeof(double4));
+    c.pos = nullptr;
+    c.flags = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    c.base = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    c.own_order = reinterpret_cast<int*>(p); p += al(n_cap * 4);
+    c.info = reinterpret_cast<int*>(p);
+    return c;
+}
+void launch_tree_cat64(hipStream_t s, const double4* pos_all, const int* seg_count, int n_seg, int seg_cap, int my_seg, double4* pos_cat, int* info) {
+    const int slots = n_seg * seg_cap;
+    hipLaunchKernelGGL(k_tree_cat64, dim3((slots + 255) / 256), dim3(256), 0, s, pos_all, seg_count, n_seg, seg_cap, my_seg, pos_cat, info);
 }
 
 void launch_tree_cat(hipStream_t s, const Shard& sh, const TreeCat& c) {

@@ -1058,7 +1058,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
         // the device-built tree unless the host build is asked for (AUTO: as for f32)
         if (cfg->method == NBODY_BRUTE_FORCE) h->cfg.math_mode = NBODY_MATH_STRICT;
         if (cfg->tree_build == NBODY_TREE_AUTO) h->cfg.tree_build = h->cfg.math_mode == NBODY_MATH_FAST ? NBODY_TREE_DEVICE : NBODY_TREE_HOST;
-        if (cfg->world_size > 1) h->cfg.tree_build = NBODY_TREE_HOST;   // (a sharded f64 world builds the replicated tree on the host)
+        if (cfg->world_size > 1 && h->cfg.math_mode != NBODY_MATH_FAST) h->cfg.tree_build = NBODY_TREE_HOST;   // (a sharded f64 world in strict math builds the replicated tree on the host; fast math: on the device, from the gathered positions)
     }
     if (h->cfg.shard_mode == NBODY_SHARD_SPATIAL) h->cfg.tree_build = NBODY_TREE_DEVICE;
     cfg = &h->cfg;

@@ -46,6 +46,7 @@ struct State {
     size_t energy_blocks = 0;
     // device-side build (NBODY_TREE_DEVICE): kernels_tree.hip instantiated for double
     void* d_tree_ws = nullptr;
+    void* d_tree_cat = nullptr;   // sharded worlds, device build: the gathered live bodies + the own-order filter's arrays
     size_t tree_ws_cap = 0;    // bodies the workspace is sized for
     int* d_tree_info = nullptr;   // [4] {nodes, flags, bodies}
     int* h_tree_info = nullptr;   // pinned
@@ -214,11 +215,18 @@ int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const 
 int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
     *fell_back = false;
     auto t0 = clk::now();
-    const size_t cap = size_t(s.d.cap);
+    const int G = s.d.n_seg;
+    const bool sharded = G > 1;   // every rank builds the world's tree from the gathered positions (fast math; kernels_tree.hip k_tree_cat64)
+    const size_t cap = size_t(s.d.cap) * size_t(G);
+    size_t tot_upper = 0;
+    for (int g = 0; g < G; ++g) tot_upper += size_t(s.count_upper[size_t(g)]);
+    if (!sharded) tot_upper = s.n_local;
     if (s.tree_ws_cap < cap) {
         if (s.d_tree_ws) (void)hipFree(s.d_tree_ws);
-        s.d_tree_ws = nullptr; s.tree_ws_cap = 0;
+        if (s.d_tree_cat) (void)hipFree(s.d_tree_cat);
+        s.d_tree_ws = nullptr; s.d_tree_cat = nullptr; s.tree_ws_cap = 0;
         HIP_TRY(h, hipMalloc(&s.d_tree_ws, nbody::tree_build_workspace_bytes(cap)));
+        if (sharded) HIP_TRY(h, hipMalloc(&s.d_tree_cat, nbody::tree_cat_bytes64(cap)));
         s.tree_ws_cap = cap;
     }
     if (!s.d_tree_info) {
@@ -231,24 +239,48 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
         HIP_TRY(h, hipMalloc(&s.d_order, cap * sizeof(int)));
         s.order_cap = cap;
     }
+    const double4* tree_pos = s.d.pos;
+    const int* tree_count = s.d.count;
+    nbody::TreeCat cat;
+    if (sharded) {
+        double4* pos_cat = nullptr;
+        cat = nbody::tree_cat_layout64(s.d_tree_cat, cap, &pos_cat);
+        nbody::launch_tree_cat64(h->stream, s.d.pos_all, s.d.seg_count, G, s.d.cap, s.d.my_seg, pos_cat, cat.info);
+        tree_pos = pos_cat;
+        tree_count = cat.info;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (s.node_cap < 2 * s.n_local + 64) {
+        if (s.node_cap < 2 * tot_upper + 64) {
             if (s.d_nodes) (void)hipFree(s.d_nodes);
             s.d_nodes = nullptr; s.node_cap = 0;
-            const size_t want = std::max<size_t>(2 * s.n_local + 64, s.dev_nodes + s.dev_nodes / 4 + 1024);
+            const size_t want = std::max<size_t>(2 * tot_upper + 64, s.dev_nodes + s.dev_nodes / 4 + 1024);
             HIP_TRY(h, hipMalloc(&s.d_nodes, want * sizeof(Node64)));
             s.node_cap = want;
         }
-        if (nbody::build_octree_device_f64(h->stream, s.d.pos, s.d.count, int(s.n_local), s.center, s.width, s.d_tree_ws, s.tree_ws_cap, s.d_nodes,
+        if (nbody::build_octree_device_f64(h->stream, tree_pos, tree_count, int(tot_upper), s.center, s.width, s.d_tree_ws, s.tree_ws_cap, s.d_nodes,
                                            int(std::min<size_t>(s.node_cap, 0x7fffffff)), s.d_order, s.d_tree_info, &s.tree_work) != 0)
             return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
         HIP_TRY(h, hipMemcpyAsync(s.h_tree_info, s.d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (sharded) HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.seg_count, sizeof(int) * size_t(G), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (s.h_tree_info[1] & 5) { *fell_back = true; return NBODY_OK; }
         if (!(s.h_tree_info[1] & 2)) break;
         s.dev_nodes = size_t(s.h_tree_info[0]);   // the array was too small: the build says how many it needs
         s.node_cap = 0;
         if (attempt == 1) return fail(h, NBODY_ERR_CAPACITY, "device octree build: node array too small twice");
+    }
+    if (sharded) {   // the live counts of every block, and the own bodies' places in the tree order
+        size_t total = 0;
+        for (int g = 0; g < G; ++g) { s.count_upper[size_t(g)] = s.h_count[g]; total += size_t(s.h_count[g]); }
+        s.dev_nodes = size_t(s.h_tree_info[0]);
+        s.n_local = size_t(s.h_count[s.d.my_seg]);
+        s.count_dirty = false;
+        s.tree_on_device = true;
+        if (nbody::launch_tree_own_order(h->stream, s.d_order, cat, int(total), s.d_tree_ws, nbody::tree_build_tmp_bytes(cap)) != 0)
+            return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
+        h->stats.tree_build_ms += ms_since(t0);
+        h->stats.tree_nodes = s.dev_nodes;
+        return fast_walk(h, s, s.d_nodes, int(s.dev_nodes), cat.own_order, int(s.n_local), nullptr, int(total));
     }
     s.dev_nodes = size_t(s.h_tree_info[0]);
     s.n_local = size_t(s.h_tree_info[2]);
@@ -270,7 +302,7 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
 
 // BarnesHutSimulation::update_forces (barnes_hut.rs:250-263): rebuild the tree (host, f64), one walk per body
 int bh_forces(NbodyHandle* h, State& s) {
-    if (h->cfg.tree_build == NBODY_TREE_DEVICE && s.d.n_seg == 1) {   // (a sharded f64 world builds on the host: create says so)
+    if (h->cfg.tree_build == NBODY_TREE_DEVICE && (s.d.n_seg == 1 || h->cfg.math_mode == NBODY_MATH_FAST)) {   // (a sharded world: fast math only, create says so)
         bool fell_back = false;
         int rc = bh_forces_device(h, s, &fell_back);
         if (rc || !fell_back) return rc;
@@ -419,7 +451,7 @@ void destroy(NbodyHandle* h) {
     if (!s) return;
     s->tree.clear();
     void* dev[] = {s->d.pos_all, s->d.vel, s->d.acc, s->d.seg_count, s->d.escaped, s->d.keep, s->d.tile_state, s->d.epoch, s->d.inter,
-                   s->d_aos, s->d_nodes, s->d_order, s->d_stack, s->d_energy, s->d_tree_ws, s->d_tree_info, s->d_split, s->d_planes};
+                   s->d_aos, s->d_nodes, s->d_order, s->d_stack, s->d_energy, s->d_tree_ws, s->d_tree_cat, s->d_tree_info, s->d_split, s->d_planes};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {s->h_count, s->h_aos, s->h_pos, s->h_tree_info, s->h_split};
     for (void* p : host) if (p) (void)hipHostFree(p);

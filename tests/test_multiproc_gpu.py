@@ -270,16 +270,19 @@ def test_f64_ranks_are_bit_equal_to_one_handle_and_the_oracle(gpu, orc, tmp_path
         assert np.array_equal(got[f].view(np.uint64), ref[f].view(np.uint64)), f
 
 
-def test_f64_fast_walk_ranks(gpu, tmp_path):
-    """NBODY_MATH_FAST on f64 ranks: the fast walk over the replicated host-built tree, to f64 rounding of the one-handle run."""
+@pytest.mark.parametrize("tree,G,n", [("host", 3, 6000), ("device", 3, 6000), ("device", 2, 40000)])
+def test_f64_fast_walk_ranks(gpu, tmp_path, tree, G, n):
+    """NBODY_MATH_FAST on f64 ranks: the fast walk over the replicated tree -- built on the host, or (round 3) by every rank
+    on the device from the gathered positions (k_tree_cat64 + the f64 device build + the own-order filter) -- to f64
+    rounding of the one-handle run with the same build, bodies leaving the box on the way."""
     nb = gpu
     from nbody_llm_amd import ranks
     sd = dict(g=1.0, g_soft=0.01, dt=5e-3, theta2=0.25)
-    cfg = world_cfg(tmp_path, 3, dict(method="bh", math="fast", tree="host"), dict(n=6000, seed=82, f64=True), sd, [["steps", 5]], box=[[0.0, 0.0, 0.0], 4.0])
-    res = launch(cfg, 3)
+    cfg = world_cfg(tmp_path, G, dict(method="bh", math="fast", tree=tree), dict(n=n, seed=82, f64=True), sd, [["steps", 5]], box=[[0.0, 0.0, 0.0], 4.0])
+    res = launch(cfg, G)
     got = ranks.gather_world(res)
     ref, s1 = single(nb, cfg)
-    assert len(got) == len(ref) < 6000
+    assert len(got) == len(ref) < n
     assert np.abs(got["position"] - ref["position"]).max() < 1e-12
     assert sum(r["interactions"] for r in res) == s1.interactions
 
