@@ -18,6 +18,7 @@ struct Tuning {
                                 // -1 from the body count (walk_plan), 0 / 1 one body per lane (k_bh_walk), 2 3 4 6 8                              [NBODY_BH_DUO]
     int bh_walk_xcd = 1;        // k_bh_walk_duo / k_bh_walk_fast64: each XCD walks one eighth of the tree order (its L2 then holds that region's deep nodes)  [NBODY_BH_XCD]
     int let_list_div = 4;       // spatial shards: export / import buffers start at (slice node capacity) / this (they grow when a step needs more)
+    int sym_ipt = 0;            // k_bf_sym: bodies per lane of a resident set: 0 from the shard's size (4 up to 10 240 bodies, else 8), 4, 8        [NBODY_SYM_IPT]
     int sym_wpb = 4;            // k_bf_sym: waves per workgroup: 4 (default), 8, 12 or 16                                           [NBODY_SYM_WPB]
     int sym_rounds = 1;         // k_bf_sym: rounds of workgroups per CU
     int sym_k = 0;              // k_bf_sym: waves (slices) per resident set; 0 = by the plan's rule
@@ -110,6 +111,7 @@ struct SymPlan {
     std::vector<int> bounds;  // K+1 cut points of a set's chunk sequence
 };
 SymPlan make_sym_plan(int n_upper);
+int sym_bodies_per_lane(size_t n);   // 8, or 4 for small shards (Tuning::sym_ipt)
 uint64_t sym_main_pairs(const SymPlan& p, size_t n);  // unordered pairs of real bodies k_bf_sym evaluates
 void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const int* d_bounds, float4* planes,
                         int n_upper, float g_soft2);

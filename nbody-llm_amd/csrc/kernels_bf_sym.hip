@@ -453,9 +453,18 @@ extern "C" int nbody_sym_read_stamps(unsigned long long* out, int n_waves) { ret
 namespace nbody {
 
 // ----------------------------------------------------------------------------------- host side
+// 8 bodies per lane of a resident set; 4 for small shards (up to 10 240 bodies): twice the waves with half the work each --
+// 4 096 bodies 22.0 -> 15.5 us, 8 192 (a rank's shard of the metric at 8 GPUs) 25.9 -> 23.4 us; from 12 288 up 8 is ahead
+int sym_bodies_per_lane(size_t n) {
+    const Tuning& t = tuning();
+    if (!t.sym_packed || t.sym_wpb != 4 || t.sym_ipt == 8) return 8;
+    if (t.sym_ipt == 4) return 4;
+    return n <= 10240 ? 4 : 8;
+}
+
 SymPlan make_sym_plan(int n_upper) {
     SymPlan p;
-    constexpr int IPT = 8;
+    const int IPT = sym_bodies_per_lane(size_t(n_upper));   // bodies per lane of a resident set
     p.ipt = IPT;
     p.A = (n_upper + 64 * IPT - 1) / (64 * IPT);
     p.sym_sets = (p.A + 1) / 2 - 1;             // ceil(A/2) - 1 sets are met symmetrically
@@ -531,6 +540,10 @@ void launch_bf_sym_main(hipStream_t s, const Shard& sh, const SymPlan& p, const 
 #else
     constexpr int dbg = 0;
 #endif
+    if (p.ipt == 4) {   // half-size resident sets (4 bodies per lane): twice the waves for small shards
+        hipLaunchKernelGGL((k_bf_sym<4, 4, 0, true>), grid, block, 0, s, sh.own_pos(), sh.own_count(), p.A, p.K, d_bounds, p.sym_sets, planes, p.plane_stride, g_soft2, p.res_combine);
+        return;
+    }
     if (tuning().sym_packed) {
         constexpr bool PKV = true;
         if (dbg == 4) {
@@ -576,6 +589,10 @@ void launch_bf_sym_tail(hipStream_t s, const Shard& sh, const SymPlan& p, float4
     if (p.sym_sets == 0) {  // no rotation pass: the resident-side planes are never written
         float4* resident0 = planes + size_t(p.sym_sets) * p.plane_stride;
         (void)hipMemsetAsync(resident0, 0, size_t(p.k_res) * p.plane_stride * sizeof(float4), s);
+        if (p.ipt == 4)
+            hipLaunchKernelGGL(k_bf_sym_rest<4>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(),
+                               sh.own_count(), p.A, planes + size_t(p.sym_sets + p.k_res) * p.plane_stride, g_soft2);
+        else
         hipLaunchKernelGGL(k_bf_sym_rest<8>, dim3(int(p.n_pad / 64)), dim3(512), 0, s, sh.own_pos(),
                            sh.own_count(), p.A, planes + size_t(p.sym_sets + p.k_res) * p.plane_stride, g_soft2);
     }

@@ -256,9 +256,10 @@ constexpr size_t kShardedSymMinBodies = 2048; // sharded: own-own symmetric + re
 
 // (re)build the symmetric kernel's plan when the number of resident sets changes
 int ensure_sym_plan(NbodyHandle* h) {
-    const int A = int((std::max<size_t>(1, h->n_local) + 511) / 512);  // (an empty shard still plans one set)
-    const int knobs = nbody::tuning().sym_wpb * 100 + nbody::tuning().sym_rounds + nbody::tuning().sym_k * 10000;
-    if (h->sym_plan.A == A && h->d_sym_bounds && h->sym_waves == knobs) return NBODY_OK;
+    const size_t set = size_t(64) * size_t(nbody::sym_bodies_per_lane(std::max<size_t>(1, h->n_local)));   // bodies of a resident set (make_sym_plan)
+    const int A = int((std::max<size_t>(1, h->n_local) + set - 1) / set);  // (an empty shard still plans one set)
+    const int knobs = nbody::tuning().sym_wpb * 100 + nbody::tuning().sym_rounds + nbody::tuning().sym_k * 10000 + nbody::tuning().sym_ipt * 1000000;
+    if (h->sym_plan.A == A && h->sym_plan.ipt * 64 == int(set) && h->d_sym_bounds && h->sym_waves == knobs) return NBODY_OK;
     h->sym_waves = knobs;
     h->sym_plan = nbody::make_sym_plan(int(std::max<size_t>(1, h->n_local)));
     nbody::SymPlan& p = h->sym_plan;
@@ -274,7 +275,9 @@ int ensure_sym_plan(NbodyHandle* h) {
             h->recv_plane0 = p.n_planes + h->cross.k_res;
             p.n_planes += h->cross.k_res + h->cross.n_recv;
         } else {  // one-sided planes for the other shards' bodies: CU-sized 12-wave workgroups
-            p.k_os = std::max(1, std::min(256, 3072 / p.A));
+            const int a_os = int((p.n_pad + 511) / 512);   // (k_bf_os keeps resident sets of 512 bodies whatever the symmetric kernel's are)
+            p.k_os = std::max(1, std::min(256, 3072 / std::max(1, a_os)));
+            p.plane_stride = std::max(p.plane_stride, size_t(a_os) * 512);   // (its padded lanes write their rows too)
             p.n_planes += p.k_os;
         }
     }
@@ -379,7 +382,7 @@ int bf_forces(NbodyHandle* h) {
         } else {
             // ... then the other shards' bodies one-sided
             ForceTimer t(h);
-            nbody::launch_bf_os(h->stream, h->sh, p.A, p.k_os, h->d_planes + size_t(p.n_planes - p.k_os) * p.plane_stride, p.plane_stride, eps2);
+            nbody::launch_bf_os(h->stream, h->sh, int((p.n_pad + 511) / 512), p.k_os, h->d_planes + size_t(p.n_planes - p.k_os) * p.plane_stride, p.plane_stride, eps2);
             timed = uint64_t(h->n_local) * uint64_t(tot - h->n_local);
         }
         h->tail_pending = true;
@@ -1157,7 +1160,7 @@ int create_impl(const NbodyConfig* cfg, NbodyHandle** out) {
         nbody::Tuning& t = h->tune;
         const struct { const char* env; int* knob; } table[] = {
             {"NBODY_BF_VARIANT", &t.bf_fast_variant}, {"NBODY_CROSS_SYM", &t.cross_sym}, {"NBODY_SYM_PACKED", &t.sym_packed},
-            {"NBODY_BH_SPLIT", &t.bh_walk_split}, {"NBODY_SYM_WPB", &t.sym_wpb}, {"NBODY_BH_DUO", &t.bh_walk_duo}, {"NBODY_BH_XCD", &t.bh_walk_xcd},
+            {"NBODY_BH_SPLIT", &t.bh_walk_split}, {"NBODY_SYM_WPB", &t.sym_wpb}, {"NBODY_SYM_IPT", &t.sym_ipt}, {"NBODY_BH_DUO", &t.bh_walk_duo}, {"NBODY_BH_XCD", &t.bh_walk_xcd},
 #ifdef NBODY_TUNING
             {"NBODY_BH_VARIANT", &t.bh_walk_variant}, {"NBODY_BH_HOT", &t.bh_hot_cap}, {"NBODY_BH_LDS_BLOCK", &t.bh_walk_lds_block},
 #endif
@@ -1789,7 +1792,7 @@ namespace {
 struct Knob { const char* name; int nbody::Tuning::*field; bool tuning_build_only; };
 const Knob kKnobs[] = {
     {"cross_sym", &nbody::Tuning::cross_sym, false}, {"sym_packed", &nbody::Tuning::sym_packed, false},
-    {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false}, {"let_list_div", &nbody::Tuning::let_list_div, false}, {"bh_walk_duo", &nbody::Tuning::bh_walk_duo, false}, {"bh_walk_xcd", &nbody::Tuning::bh_walk_xcd, false},
+    {"bf_fast_variant", &nbody::Tuning::bf_fast_variant, false}, {"sym_wpb", &nbody::Tuning::sym_wpb, false}, {"sym_ipt", &nbody::Tuning::sym_ipt, false}, {"let_list_div", &nbody::Tuning::let_list_div, false}, {"bh_walk_duo", &nbody::Tuning::bh_walk_duo, false}, {"bh_walk_xcd", &nbody::Tuning::bh_walk_xcd, false},
     {"sym_rounds", &nbody::Tuning::sym_rounds, false}, {"sym_k", &nbody::Tuning::sym_k, false},
     {"sym_min_bodies", &nbody::Tuning::sym_min_bodies, false}, {"sym_reduce_split", &nbody::Tuning::sym_reduce_split, false},
     {"cross_slots", &nbody::Tuning::cross_slots, false}, {"cross_ipt", &nbody::Tuning::cross_ipt, false},
