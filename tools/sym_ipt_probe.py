@@ -4,7 +4,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
 nb = graft.load_package()
-for n in (4096, 8192, 12288, 16384, 24576, 32768, 65536):
+for n in (8192, 10240, 12288, 16384, 20480, 24576, 32768, 49152, 65536):
     ics = nb.plummer(n)
     for ipt in (8, 4):
         sim = nb.Simulation(ics, (0, 0, 0), 64.0, method=nb.BRUTE_FORCE, math_mode=nb.FAST, tuning={"sym_ipt": ipt})
