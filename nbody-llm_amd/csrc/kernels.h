@@ -224,7 +224,7 @@ int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_u
 int tree_emit_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, float width, void* workspace, size_t n_cap,
                      float4* nodes, int node_cap, int* order, int* out_info, int want_hot, const int* edge, const TreeSplitReq* split = nullptr);
 // the two halves of tree_emit_sorted, for the spatial-shard build (the nodes are emitted after an exchange, at an offset
-// in the global-index array, with each node's parent and depth)
+// given by *node_offset, with each node's parent and depth)
 int tree_scan_sorted(hipStream_t s, const float4* pos, const int* d_count, int n_upper, void* workspace, size_t n_cap, int* out_info,
                      const int* edge, const float4* weight_src = nullptr /* acc: .w = last walk's visit count */);
 // the weight a body's visit count stands for in the balance of spatial shards (>= 1; scaled so that 2^31 is far away)

@@ -17,7 +17,7 @@
 //     skip link the first node behind them: every rank works out what it adds to every earlier rank's spanning cells
 //     (k_let_contrib), one all-gather of those small tables, and everybody knows all spanning cells (k_let_finalize);
 //   * everything else is private to a rank's slice.  A partner needs a private node only if one of its bodies can get
-//     there, i.e. if it can OPEN every ancestor: k_let_open_masks / k_let_flag_pack test the ancestors against the
+//     there, i.e. if it can OPEN every ancestor: k_let_open_masks / k_let_flag_count test the ancestors against the
 //     boxes the partners' bodies lie in (opening test of barnes_hut.rs:192 with the box's nearest point) and write one
 //     list of records per partner,
 //     one variable-size send/recv round; the receiver lays the nodes it HOLDS -- its slice and the imports -- out in the order

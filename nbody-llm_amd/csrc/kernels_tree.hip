@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_tree_emit(const unsigned long long* __r
     }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = *count;
-    // spatial shards: the slice goes straight to its place in the global-index array (indices and links shifted)
+    // node_offset (spatial shards pass 0 and shift on the wire): indices and links of the slice shifted by it
     const int off = node_offset ? *node_offset : 0;
     if (n == 0) {  // the reference's empty root (barnes_hut.rs:145)
         if (node_offset) { if (idx == 0) { out_info[0] = 0; out_info[2] = 0; } return; }   // (a rank without bodies adds nothing to the world's tree)

@@ -202,7 +202,7 @@ def test_device_tree_trajectory_stays_with_the_host_tree_trajectory(gpu):
 @pytest.mark.parametrize("clump", [600, 3000, 6000])
 def test_a_clump_inside_one_level_16_cell(gpu, orc, clump):
     """The device build's radix sort covers the top 16 levels of the keys; bodies that share them are finished per group --
-    a pair by one thread, a clump of hundreds by a workgroup (k_tree_big_groups, up to 4096), and beyond that the build says
+    a pair by one thread, a clump of hundreds by a workgroup (sort_big_group inside k_tree_ties, up to 4096), and beyond that the build says
     so with a flag of its own and the single-GPU step builds on the host.  Either way the tree is the reference's: node
     counts and accelerations equal the oracle's (strict walk: bit for bit)."""
     nb = gpu
