@@ -217,7 +217,7 @@ namespace nbody64 { struct Node64; }
 namespace nbody {
 int build_octree_device_f64(hipStream_t s, const double4* pos, const int* d_count, int n_upper, const double center[3], double width,
                             void* workspace, size_t n_cap, nbody64::Node64* nodes, int node_cap, int* order, int* out_info,
-                            TreeDevWork* work);
+                            TreeDevWork* work, const TreeSplitReq* split = nullptr);
 // the build in two halves (spatial shards need the sorted keys of all ranks' ends before the second one)
 int tree_sort_keys(hipStream_t s, const float4* pos, const int* d_count, int n_upper, const float center[3], float width,
                    void* workspace, size_t n_cap, int* out_info, TreeDevWork* work);

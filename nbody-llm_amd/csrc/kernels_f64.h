@@ -64,7 +64,8 @@ struct WalkSplit64 {
 };
 constexpr int kMaxAnc64 = 192;
 void launch_bh_walk_fast(hipStream_t s, const Dev& d, const Node64* nodes, int n_nodes, const int* order, int n_order, double g, double eps2,
-                         double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split, int bodies_per_lane = 1);
+                         double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split, int bodies_per_lane = 1,
+                         const double* kick_dt = nullptr /* fuse integrate_after_force into the plane reduction */, int* kicked = nullptr);
 void launch_energy(hipStream_t s, const Dev& d, int n_upper, double eps2, double* out2);
 
 }  // namespace nbody64

@@ -377,8 +377,10 @@ __global__ __launch_bounds__(kWalkBlock) void k_bh_walk_fast64(const Node64* __r
     add_counts(counters, n_acc, n_vis);
 }
 
+// KICK: integrate_after_force (shared.rs:141-148) rides along (k_kick_drift's arithmetic, one launch less per step)
+template <bool KICK>
 __global__ __launch_bounds__(256) void k_bh_reduce64(const double4* __restrict__ planes, int n_seg, size_t plane_stride, const int* __restrict__ order,
-                                                     int n_order, double4* __restrict__ acc) {
+                                                     int n_order, double4* __restrict__ acc, double4* __restrict__ pos, double4* __restrict__ vel, double dt) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_order) return;
     double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -386,7 +388,19 @@ __global__ __launch_bounds__(256) void k_bh_reduce64(const double4* __restrict__
         const double4 v = planes[size_t(k) * plane_stride + t];
         sx += v.x; sy += v.y; sz += v.z;
     }
-    acc[order[t]] = make_double4(sx, sy, sz, 0.0);
+    const int b = order[t];
+    acc[b] = make_double4(sx, sy, sz, 0.0);
+    if (KICK) {
+        double4 p = pos[b], v = vel[b];
+        v.x += sx * dt;
+        v.y += sy * dt;
+        v.z += sz * dt;
+        p.x += (v.x * 0.5) * dt;
+        p.y += (v.y * 0.5) * dt;
+        p.z += (v.z * 0.5) * dt;
+        vel[b] = v;
+        pos[b] = p;
+    }
 }
 
 // ---- diagnostics: KE and pair-potential row sums, per-block partials {KE, sum_j m_i m_j / d_ij}
@@ -468,7 +482,8 @@ void launch_bh_walk(hipStream_t s, const Dev& d, const Node64* nodes, int n_node
                            stack, stack_stride);
 }
 void launch_bh_walk_fast(hipStream_t s, const Dev& d, const Node64* nodes, int n_nodes, const int* order, int n_order, double g, double eps2,
-                         double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split, int bodies_per_lane) {
+                         double theta2, unsigned long long* counters, int leaf_direct, const WalkSplit64& split, int bodies_per_lane, const double* kick_dt, int* kicked) {
+    if (kicked) *kicked = 0;
     if (n_order <= 0) return;
     const int bpl = bodies_per_lane >= 6 ? 6 : bodies_per_lane >= 4 ? 4 : bodies_per_lane == 3 ? 3 : bodies_per_lane == 2 ? 2 : 1;
     const int gx = int(blocks_for((n_order + bpl - 1) / bpl, kWalkBlock)), gx8 = (gx + 7) / 8 * 8;
@@ -479,8 +494,16 @@ void launch_bh_walk_fast(hipStream_t s, const Dev& d, const Node64* nodes, int n
     if (leaf_direct) WALK64_B(true); else WALK64_B(false);
 #undef WALK64_B
 #undef WALK64
-    if (split.n_seg > 1)
-        hipLaunchKernelGGL(k_bh_reduce64, dim3(blocks_for(n_order, 256)), dim3(256), 0, s, split.planes, split.n_seg, split.plane_stride, order, n_order, d.acc);
+    if (split.n_seg > 1) {
+        if (kick_dt) {   // (every own body is in `order` exactly once: the kick reaches them all)
+            hipLaunchKernelGGL(k_bh_reduce64<true>, dim3(blocks_for(n_order, 256)), dim3(256), 0, s, split.planes, split.n_seg, split.plane_stride, order, n_order,
+                               d.acc, d.pos, d.vel, *kick_dt);
+            if (kicked) *kicked = 1;
+        } else {
+            hipLaunchKernelGGL(k_bh_reduce64<false>, dim3(blocks_for(n_order, 256)), dim3(256), 0, s, split.planes, split.n_seg, split.plane_stride, order, n_order,
+                               d.acc, d.pos, d.vel, 0.0);
+        }
+    }
 }
 void launch_energy(hipStream_t s, const Dev& d, int n_upper, double eps2, double* out2) {
     if (n_upper <= 0) return;

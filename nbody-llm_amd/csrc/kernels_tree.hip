@@ -735,11 +735,11 @@ int build_octree_device(hipStream_t s, const float4* pos, const int* d_count, in
 // (against the reference's sequential f64 folds they differ in the last bits only), 64-byte node records.
 int build_octree_device_f64(hipStream_t s, const double4* pos, const int* d_count, int n_upper, const double center[3], double width,
                             void* workspace, size_t n_cap, nbody64::Node64* nodes, int node_cap, int* order, int* out_info,
-                            TreeDevWork* work) {
+                            TreeDevWork* work, const TreeSplitReq* split) {
     if (sort_keys_t<double4, double>(s, pos, d_count, n_upper, center, width, workspace, n_cap, out_info, work) != 0) return -1;
     if (scan_sorted_t<double4>(s, pos, d_count, n_upper, workspace, n_cap, out_info, nullptr, nullptr) != 0) return -1;
     return emit_nodes_t<double4, double, nbody64::Node64>(s, pos, d_count, width, workspace, n_cap, nodes, node_cap, node_cap, order, out_info, 0,
-                                                          nullptr, nullptr, nullptr, nullptr);
+                                                          nullptr, nullptr, nullptr, nullptr, split);
 }
 
 void launch_tree_split_anc(hipStream_t s, const TreeDevWork& work, int n, int n_nodes, int n_split, int* first,

@@ -46,6 +46,8 @@ struct State {
     size_t energy_blocks = 0;
     // device-side build (NBODY_TREE_DEVICE): kernels_tree.hip instantiated for double
     void* d_tree_ws = nullptr;
+    const double* kick_dt = nullptr;   // inside a step: the dt the force pass may apply itself (fast walk, split node range)
+    int kicked = 0;
     void* d_tree_cat = nullptr;   // sharded worlds, device build: the gathered live bodies + the own-order filter's arrays
     size_t tree_ws_cap = 0;    // bodies the workspace is sized for
     int* d_tree_info = nullptr;   // [4] {nodes, flags, bodies}
@@ -160,7 +162,8 @@ int ensure_stack(NbodyHandle* h, State& s, int levels) {   // the nested sums' s
 // few ten thousand bodies still fill the chip.  `host_nodes` != nullptr: the split points' ancestors are listed here from
 // the host-built tree; nullptr: by k_tree_split_anc from the device build's arrays (n_tree bodies).
 constexpr int kMaxSplit = 64;
-int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const int* order, int n_order, const nbody::NodeRecT<double>* host_nodes, int n_tree) {
+int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const int* order, int n_order, const nbody::NodeRecT<double>* host_nodes, int n_tree,
+              int k_done = 0 /* > 0: the split points of this many segments are on the device already (they rode in the build) */) {
     constexpr size_t kSplitInts = kMaxSplit + 1 + kMaxSplit + size_t(kMaxSplit) * kMaxAnc64;
     if (!s.d_split) {
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_split), kSplitInts * sizeof(int)));
@@ -169,11 +172,13 @@ int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const 
     const nbody::WalkPlan plan = nbody::walk_plan(size_t(n_order), true, kMaxSplit, float(s.theta2));   // (bodies per lane x segments: kernels.h)
     int K = plan.segments;
     while (nbody::tuning().bh_walk_split <= 0 && K > 1 && K * 16 > n_nodes) K /= 2;
+    if (k_done > 0) K = k_done;
     if (n_order == 0 || n_nodes <= 0) return NBODY_OK;
     int* first = s.d_split;
     int* n_anc = s.d_split + kMaxSplit + 1;
     int* anc = s.d_split + kMaxSplit + 1 + kMaxSplit;
-    if (host_nodes) {
+    if (k_done > 0) {
+    } else if (host_nodes) {
         int* hf = s.h_split;
         int* hn = hf + kMaxSplit + 1;
         int* ha = hn + kMaxSplit;
@@ -203,7 +208,7 @@ int fast_walk(NbodyHandle* h, State& s, const Node64* nodes, int n_nodes, const 
     {
         ForceTimer t(h);
         launch_bh_walk_fast(h->stream, s.d, nodes, n_nodes, order, n_order, s.g, s.g_soft * s.g_soft, s.theta2, h->d_counters,
-                            h->cfg.leaf_mode == NBODY_LEAF_DIRECT ? 1 : 0, sp, std::min(3, plan.bodies_per_lane));   // (64-byte records, doubles in registers: beyond three per lane the f64 walk loses again -- tools/f64_walk_probe.py)
+                            h->cfg.leaf_mode == NBODY_LEAF_DIRECT ? 1 : 0, sp, std::min(3, plan.bodies_per_lane), s.kick_dt, &s.kicked);   // (64-byte records, doubles in registers: beyond three per lane the f64 walk loses again -- tools/f64_walk_probe.py)
     }
     HIP_TRY(h, hipGetLastError());
     return NBODY_OK;
@@ -249,6 +254,21 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
         tree_pos = pos_cat;
         tree_count = cat.info;
     }
+    // one shard, fast math: the walk's split points ride in the build's last launch (kernels.h TreeSplitReq)
+    nbody::TreeSplitReq req;
+    int k_pre = 0;
+    if (!sharded && h->cfg.math_mode == NBODY_MATH_FAST && tot_upper > 0) {
+        constexpr size_t kSplitInts = kMaxSplit + 1 + kMaxSplit + size_t(kMaxSplit) * kMaxAnc64;
+        if (!s.d_split) {
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_split), kSplitInts * sizeof(int)));
+            HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&s.h_split), kSplitInts * sizeof(int), hipHostMallocDefault));
+        }
+        int K = nbody::walk_plan(tot_upper, true, kMaxSplit, float(s.theta2)).segments;
+        while (nbody::tuning().bh_walk_split <= 0 && K > 1 && size_t(K) * 16 > tot_upper) K /= 2;   // (a tree has at least as many nodes as bodies)
+        req.n_split = K; req.first = s.d_split; req.n_anc = s.d_split + kMaxSplit + 1; req.anc = s.d_split + kMaxSplit + 1 + kMaxSplit;
+        req.max_anc = kMaxAnc64; req.info = s.d_tree_info; req.poison = nullptr;
+        k_pre = K;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (s.node_cap < 2 * tot_upper + 64) {
             if (s.d_nodes) (void)hipFree(s.d_nodes);
@@ -258,7 +278,7 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
             s.node_cap = want;
         }
         if (nbody::build_octree_device_f64(h->stream, tree_pos, tree_count, int(tot_upper), s.center, s.width, s.d_tree_ws, s.tree_ws_cap, s.d_nodes,
-                                           int(std::min<size_t>(s.node_cap, 0x7fffffff)), s.d_order, s.d_tree_info, &s.tree_work) != 0)
+                                           int(std::min<size_t>(s.node_cap, 0x7fffffff)), s.d_order, s.d_tree_info, &s.tree_work, k_pre ? &req : nullptr) != 0)
             return fail(h, NBODY_ERR_HIP, "device octree build: rocPRIM call failed");
         HIP_TRY(h, hipMemcpyAsync(s.h_tree_info, s.d_tree_info, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         if (sharded) HIP_TRY(h, hipMemcpyAsync(s.h_count, s.d.seg_count, sizeof(int) * size_t(G), hipMemcpyDeviceToHost, h->stream));
@@ -288,7 +308,7 @@ int bh_forces_device(NbodyHandle* h, State& s, bool* fell_back) {
     s.tree_on_device = true;
     h->stats.tree_build_ms += ms_since(t0);
     h->stats.tree_nodes = s.dev_nodes;
-    if (h->cfg.math_mode == NBODY_MATH_FAST) return fast_walk(h, s, s.d_nodes, int(s.dev_nodes), s.d_order, int(s.n_local), nullptr, int(s.n_local));
+    if (h->cfg.math_mode == NBODY_MATH_FAST) return fast_walk(h, s, s.d_nodes, int(s.dev_nodes), s.d_order, int(s.n_local), nullptr, int(s.n_local), k_pre);
     const bool direct = h->cfg.leaf_mode == NBODY_LEAF_DIRECT;
     if (!direct) { int rc = ensure_stack(h, s, 45); if (rc) return rc; }   // (the device build goes to 42 levels)
     {
@@ -393,9 +413,11 @@ int step_impl(NbodyHandle* h, State& s, double dt) {
     HIP_TRY(h, hipGetLastError());
     int rc = exchange(h, s);                                        // sharded: every block's positions and live count
     if (rc) return rc;
+    s.kick_dt = &dt; s.kicked = 0;                                  // (the fast walk's plane reduction can take the kick along)
     rc = forces(h, s);                                              // update_forces
+    s.kick_dt = nullptr;
     if (rc) return rc;
-    launch_kick_drift(h->stream, s.d, int(s.n_local), dt);          // integrate_after_force
+    if (!s.kicked) launch_kick_drift(h->stream, s.d, int(s.n_local), dt);   // integrate_after_force
     HIP_TRY(h, hipGetLastError());
     s.elapsed += dt;                                                // elapsed += dt
     h->stats.steps += 1;
