@@ -302,6 +302,13 @@ int nbody_host_cross_plan(int rank, int world, int seg_cap, int n_own, int* ipt,
 int nbody_host_exchange_layout(const int* matrix, int world, int rank, long long clamp, int packed_send, size_t send_stride,
                                size_t* out_at, size_t* n_out, size_t* in_at, size_t* n_in, size_t* total_in);
 
+/* ---- host-only entry (no device needed): the launch shapes the library derives from a body count ---- */
+/* With the default knobs: the fast Barnes-Hut walk's bodies per lane and node-range segments for `n_bodies` walked bodies at
+ * opening angle theta2 (kernels.h walk_plan), and the symmetric brute-force kernel's bodies per lane of a resident set
+ * (sym_bodies_per_lane).  What tools and tests read the plan with; out[0..2] = {walk bodies per lane, walk segments, sym
+ * bodies per lane}. */
+int nbody_host_launch_plan(size_t n_bodies, float theta2, int fast_math, int out[3]);
+
 /* ---- host-only entry (no device needed): the octree build alone ------------------------------ */
 /* BarnesHutSimulation::build_tree (barnes_hut.rs:143-183) + linearisation, as the Barnes-Hut step
  * runs it.  pos4 = n records {x,y,z,m}.  Output arrays hold `cap` nodes (com_mass: 4 floats per

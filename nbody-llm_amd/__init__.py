@@ -72,7 +72,7 @@ DECLARED_SYMBOLS = [
     "nbody_download_ids", "nbody_let_stats", "nbody_debug_let_phase", "nbody_debug_let_exchange", "nbody_debug_let_set_prune",
     "nbody_debug_let_bounds", "nbody_debug_let_set_balance",
     "nbody_comm_local_id", "nbody_comm_transport", "nbody_host_exchange_layout",
-    "nbody_set_tuning", "nbody_get_tuning", "nbody_is_tuning_build", "nbody_tree_export_cells",
+    "nbody_set_tuning", "nbody_get_tuning", "nbody_is_tuning_build", "nbody_tree_export_cells", "nbody_host_launch_plan",
 ]
 
 
@@ -169,6 +169,7 @@ _sig("nbody_debug_let_set_prune", _i, _H, _i)
 _sig("nbody_debug_let_bounds", _i, _H, C.c_void_p)
 _sig("nbody_debug_let_set_balance", _i, _H, _i)
 _sig("nbody_host_exchange_layout", _i, C.c_void_p, _i, _i, C.c_longlong, _i, _sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_sz))
+_sig("nbody_host_launch_plan", _i, _sz, _f, _i, C.POINTER(_i))
 _sig("nbody_set_tuning", _i, _H, C.c_char_p, _i)
 _sig("nbody_get_tuning", _i, _H, C.c_char_p, C.POINTER(_i))
 _sig("nbody_is_tuning_build", _i)
@@ -193,6 +194,15 @@ class tuning_defaults:
     def __exit__(self, *a):
         _default_tuning.clear()
         _default_tuning.update(self.saved)
+
+
+def launch_plan(n_bodies: int, theta2: float = 0.25, fast_math: bool = True) -> dict:
+    """The launch shapes the library derives from a body count with its default knobs (nbody_host_launch_plan)."""
+    out = (C.c_int * 3)()
+    rc = lib.nbody_host_launch_plan(int(n_bodies), float(theta2), int(bool(fast_math)), out)
+    if rc != 0:
+        raise NbodyError(rc, "nbody_host_launch_plan")
+    return {"walk_bodies_per_lane": out[0], "walk_segments": out[1], "sym_bodies_per_lane": out[2]}
 
 
 def is_tuning_build() -> bool:

@@ -1966,6 +1966,14 @@ int nbody_host_cross_plan(int rank, int world, int seg_cap, int n_own, int* ipt,
 
 // Host-only entry (no device needed): where the variable-size rounds of the spatial step (migrants, tree nodes) put their
 // messages, from the all-gathered G x G count matrix -- the arithmetic sender and receiver of every pair share.
+int nbody_host_launch_plan(size_t n_bodies, float theta2, int fast_math, int out[3]) {
+    if (!out) return NBODY_ERR_INVALID;
+    nbody::bind_tuning(nullptr);   // (the library's defaults, not some handle's knobs)
+    const nbody::WalkPlan p = nbody::walk_plan(n_bodies, fast_math != 0, 64, theta2);
+    out[0] = p.bodies_per_lane; out[1] = p.segments; out[2] = nbody::sym_bodies_per_lane(n_bodies);
+    return NBODY_OK;
+}
+
 int nbody_host_exchange_layout(const int* matrix, int world, int rank, long long clamp, int packed_send, size_t send_stride,
                                size_t* out_at, size_t* n_out, size_t* in_at, size_t* n_in, size_t* total_in) {
     if (!matrix || world < 1 || world > 16 || rank < 0 || rank >= world || !out_at || !n_out || !in_at || !n_in) return NBODY_ERR_INVALID;
